@@ -1,0 +1,115 @@
+"""ctypes access to oracle/liboracle.so (the C restatement).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, the smoke check and the benchmark's CPU-baseline leg, never by slam_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_u32 = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oracle_sample.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, _i32]
+        L.oracle_mt_raw.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, _u32]
+        L.oracle_eight_point.argtypes = [_f64, _f64, C.c_int, _f64]
+        L.oracle_ransac.argtypes = [_f64, _f64, C.c_int, _i32, C.c_int, C.c_double, C.c_void_p, _i32, _f64,
+                                    C.POINTER(C.c_int32), _f64, C.c_void_p, C.c_int]
+        L.oracle_normalize_points.argtypes = [_f64, C.c_int, _f64, _f64]
+        L.oracle_triangulate.argtypes = [_f64, _f64, _f64, _f64, C.c_int64, _f64, C.c_int]
+        L.oracle_pose_candidates.argtypes = [_f64, _f64, _f64]
+        L.oracle_pose_from_E.argtypes = [_f64, _f64, _f64, _f64, C.c_int64, _f64, _f64, _i32,
+                                         C.POINTER(C.c_int32), C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _c(a, dt=np.float64):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def sample(N, H, k=8, seed_base=0x1337BEEF, it0=0):
+    idx = np.empty((H, k), dtype=np.int32)
+    assert lib().oracle_sample(seed_base, it0, H, N, k, idx) == 0
+    return idx
+
+
+def mt_raw(H, count, seed_base=0x1337BEEF, it0=0):
+    out = np.empty((H, count), dtype=np.uint32)
+    lib().oracle_mt_raw(seed_base, it0, H, count, out)
+    return out
+
+
+def eight_point(p0, p1):
+    p0, p1 = _c(p0), _c(p1)
+    F = np.empty((3, 3))
+    assert lib().oracle_eight_point(p0, p1, len(p0), F) == 0
+    return F
+
+
+def ransac(p0, p1, idx, thr=0.005, threads=1, want_F=True, want_mask=True):
+    p0, p1, idx = _c(p0), _c(p1), _c(idx, np.int32)
+    H, N = len(idx), len(p0)
+    Fs = np.empty((H, 3, 3)) if want_F else None
+    counts = np.empty(H, dtype=np.int32)
+    errsums = np.empty(H)
+    bi = C.c_int32(-1)
+    bF = np.empty((3, 3))
+    mask = np.empty(N, dtype=np.uint8) if want_mask else None
+    rc = lib().oracle_ransac(p0, p1, N, idx, H, thr, Fs.ctypes.data if want_F else None, counts, errsums,
+                             C.byref(bi), bF, mask.ctypes.data if want_mask else None, threads)
+    assert rc == 0
+    return dict(F=Fs, counts=counts, errsums=errsums, best_index=int(bi.value), best_F=bF,
+                best_mask=None if mask is None else mask.astype(bool),
+                best_count=int(counts[bi.value]), best_errsum=float(errsums[bi.value]))
+
+
+def normalize_points(p):
+    p = _c(p)
+    out = np.empty_like(p)
+    T = np.empty((3, 3))
+    lib().oracle_normalize_points(p, len(p), out, T)
+    return out, T
+
+
+def triangulate(P0, P1, p0, p1, threads=1):
+    P0, P1 = _c(np.asarray(P0)[:3]), _c(np.asarray(P1)[:3])
+    p0, p1 = _c(p0), _c(p1)
+    X = np.empty((len(p0), 3))
+    lib().oracle_triangulate(P0, P1, p0, p1, len(p0), X, threads)
+    return X
+
+
+def pose_candidates(E):
+    Rs = np.empty((4, 3, 3))
+    ts = np.empty((4, 3))
+    lib().oracle_pose_candidates(_c(E), Rs, ts)
+    return Rs, ts
+
+
+def pose_from_E(E, K, p0, p1, threads=1):
+    p0, p1 = _c(p0), _c(p1)
+    pose = np.empty((4, 4))
+    X = np.empty((len(p0), 3))
+    counts = np.empty(4, dtype=np.int32)
+    w = C.c_int32(-1)
+    lib().oracle_pose_from_E(_c(E), _c(K), p0, p1, len(p0), pose, X, counts, C.byref(w), threads)
+    return pose, X, counts, int(w.value)

@@ -1,0 +1,88 @@
+"""Synthetic two-view correspondences for tests and benchmarks.
+
+Deterministic (numpy PCG64 via ``default_rng(seed)``): a camera with KITTI-like
+intrinsics looks at 3D points uniform in its frustum, moves by a small rotation
+and a unit, mostly forward translation, and observes them again with Gaussian
+pixel noise; a fraction of second-image points is replaced by uniform clutter.
+
+World/pose conventions follow the reference's camera model so that the data is
+a faithful input for its pose recovery: the second camera has rotation ``R`` and
+centre ``t`` in world (=first camera) coordinates and projects with
+``K [R^T | -R^T t]`` (reference: src/epipolar.py:117-118, src/util.py:30-37).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+KITTI_K = np.array([[718.856, 0.0, 607.19],
+                    [0.0, 718.856, 185.22],
+                    [0.0, 0.0, 1.0]])
+KITTI_SIZE = (1241.0, 376.0)
+
+# intrinsics hard-coded by the reference driver (custom_slam.py:260-262)
+REFERENCE_K = np.array([[984.2439, 0.0, 690.0],
+                        [0.0, 980.8141, 233.1966],
+                        [0.0, 0.0, 1.0]])
+REFERENCE_SIZE = (1392.0, 512.0)
+
+
+def _rotation(axis, angle):
+    axis = axis / np.linalg.norm(axis)
+    x, y, z = axis
+    c, s = np.cos(angle), np.sin(angle)
+    C = 1.0 - c
+    return np.array([[c + x * x * C, x * y * C - z * s, x * z * C + y * s],
+                     [y * x * C + z * s, c + y * y * C, y * z * C - x * s],
+                     [z * x * C - y * s, z * y * C + x * s, c + z * z * C]])
+
+
+def make_pair(n, outlier_frac=0.3, seed=0, K=KITTI_K, size=KITTI_SIZE,
+              noise_px=0.5, max_rot_deg=3.0):
+    """Return a dict with pixel matches ``pts0, pts1`` (n,2), the inlier flags,
+    and the true motion (R, t as the reference defines them)."""
+    rng = np.random.default_rng(seed)
+    w, h = size
+    # motion: rotation <= max_rot_deg about a random axis; unit translation mostly +z
+    axis = rng.normal(size=3)
+    angle = np.deg2rad(max_rot_deg) * rng.uniform(0.2, 1.0)
+    R = _rotation(axis, angle)
+    t = np.array([rng.normal(0, 0.15), rng.normal(0, 0.05), 1.0])
+    t /= np.linalg.norm(t)
+
+    Kinv = np.linalg.inv(K)
+    pts0 = np.empty((n, 2))
+    pts1 = np.empty((n, 2))
+    X = np.empty((n, 3))
+    filled = 0
+    while filled < n:
+        m = (n - filled) * 2 + 16
+        uv = np.column_stack([rng.uniform(0, w, m), rng.uniform(0, h, m), np.ones(m)])
+        depth = rng.uniform(5.0, 50.0, m)
+        P = (uv @ Kinv.T) * depth[:, None]            # points in camera-0 frame
+        q = (P - t) @ R                               # R^T (P - t), camera-1 frame
+        ok = q[:, 2] > 1.0
+        proj = q @ K.T
+        uv1 = proj[:, :2] / proj[:, 2:3]
+        ok &= (uv1[:, 0] >= 0) & (uv1[:, 0] < w) & (uv1[:, 1] >= 0) & (uv1[:, 1] < h)
+        take = min(int(ok.sum()), n - filled)
+        sel = np.flatnonzero(ok)[:take]
+        pts0[filled:filled + take] = uv[sel, :2]
+        pts1[filled:filled + take] = uv1[sel]
+        X[filled:filled + take] = P[sel]
+        filled += take
+    pts0 += rng.normal(0, noise_px, pts0.shape)
+    pts1 += rng.normal(0, noise_px, pts1.shape)
+    inlier = np.ones(n, dtype=bool)
+    n_out = int(round(outlier_frac * n))
+    if n_out:
+        out_idx = rng.choice(n, n_out, replace=False)
+        pts1[out_idx] = np.column_stack([rng.uniform(0, w, n_out), rng.uniform(0, h, n_out)])
+        inlier[out_idx] = False
+    return {"pts0": pts0, "pts1": pts1, "inlier": inlier, "R": R, "t": t, "X": X, "K": np.array(K)}
+
+
+def essential_from_motion(R, t):
+    """E (Frobenius-normalised) with x1^T E x0 = 0 for the camera model above."""
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = R.T @ tx
+    return E / np.linalg.norm(E)

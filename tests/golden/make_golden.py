@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the reference itself.
+
+Run in the build container only (the reference tree does not exist on the GPU
+box):   cd /tmp && MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+The reference modules are imported from /root/reference unchanged.  Its import
+chain names three viewer libraries the hot path never calls (cv2, pangolin,
+OpenGL); empty placeholder modules satisfy those imports, and the driver
+script's request for an interactive matplotlib backend is ignored.  Every array
+stored here is either an input we generated or an output the reference's own
+functions returned for it; no reference source text is stored.
+"""
+import contextlib
+import io
+import math
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from slam_amd import synth  # noqa: E402  (build-owned input generator)
+
+for _m in ("cv2", "pangolin", "OpenGL", "OpenGL.GL"):
+    sys.modules[_m] = types.ModuleType(_m)
+import matplotlib  # noqa: E402
+
+matplotlib.use = lambda *a, **k: None
+sys.path.insert(0, "/root/reference")
+# the repo ships its own drop-in package called `src`; make sure the reference's wins here
+for _k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+    del sys.modules[_k]
+from src import epipolar, logger, triangulation, util  # noqa: E402
+import custom_slam  # noqa: E402
+
+assert epipolar.__file__.startswith("/root/reference"), epipolar.__file__
+logger.set_log_level("WARN")
+
+SEED_BASE = 0x1337BEEF
+THRESH = 0.005
+
+
+def draw(N, it, k=8):
+    random.seed(SEED_BASE + it)
+    return random.sample(range(N), k)
+
+
+def gen_sampler():
+    out = {}
+    for N in (8, 9, 10, 12, 21, 22, 64, 85, 86, 100, 255, 256, 257, 1000, 2048, 4096, 4097, 65535, 65536, 1 << 20):
+        its = list(range(64)) + [999, 1000, 2047, 65535, 1 << 20, (1 << 32) - SEED_BASE - 1, (1 << 32) - SEED_BASE, (1 << 32) - SEED_BASE + 5]
+        out[f"its_{N}"] = np.array(its, dtype=np.int64)
+        out[f"idx_{N}"] = np.array([draw(N, it) for it in its], dtype=np.int32)
+    # k = 6 is what the tracking RANSAC draws (src/triangulation.py:155)
+    for N in (6, 20, 21, 22, 300):
+        its = list(range(32))
+        out[f"k6_its_{N}"] = np.array(its, dtype=np.int64)
+        out[f"k6_idx_{N}"] = np.array([draw(N, it, 6) for it in its], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
+
+
+def normalized_pair(n, outlier_frac, seed, K=synth.KITTI_K, size=synth.KITTI_SIZE):
+    d = synth.make_pair(n, outlier_frac, seed, K=K, size=size)
+    n0, T0 = custom_slam.normalize_points(d["pts0"])
+    n1, T1 = custom_slam.normalize_points(d["pts1"])
+    return d, n0, T0, n1, T1
+
+
+def gen_normalize():
+    out = {}
+    for i, (n, seed) in enumerate([(8, 11), (100, 12), (4096, 2)]):
+        d = synth.make_pair(n, 0.3, seed)
+        for j, p in enumerate((d["pts0"], d["pts1"])):
+            q, T = custom_slam.normalize_points(p)
+            out[f"in_{i}_{j}"] = p
+            out[f"pts_{i}_{j}"] = q
+            out[f"T_{i}_{j}"] = T
+    np.savez_compressed(os.path.join(HERE, "normalize.npz"), **out)
+
+
+def gen_solve():
+    out = {}
+    a = np.array([[-1, -.5], [.3, .9], [1.2, -.7], [-.4, .2], [.8, .6], [-1.1, 1], [.1, -1.3], [.6, .05]])
+    b = np.array([[-.9, -.45], [.35, .8], [1.1, -.75], [-.5, .25], [.85, .5], [-1, 1.1], [.15, -1.2], [.5, .1]])
+    out["kat_a"], out["kat_b"] = a, b
+    out["kat_F"] = epipolar.calculate_fundamental_matrix(a, b)
+    # minimal (8-point) solves on index sets drawn the way the RANSAC loop draws them
+    d, n0, T0, n1, T1 = normalized_pair(256, 0.3, 21)
+    H = 96
+    idx = np.array([draw(256, it) for it in range(H)], dtype=np.int32)
+    F = np.array([epipolar.calculate_fundamental_matrix(n0[list(i)], n1[list(i)]) for i in idx])
+    out["min_p0"], out["min_p1"], out["min_idx"], out["min_F"] = n0, n1, idx, F
+    # over-determined solves (the function accepts M >= 8: src/epipolar.py:23)
+    for M in (9, 12, 40, 200):
+        dd, m0, _, m1, _ = normalized_pair(M, 0.0, 30 + M)
+        out[f"over_p0_{M}"], out[f"over_p1_{M}"] = m0, m1
+        out[f"over_F_{M}"] = epipolar.calculate_fundamental_matrix(m0, m1)
+    np.savez_compressed(os.path.join(HERE, "solve.npz"), **out)
+
+
+def ransac_trace(n0, n1, iterations):
+    """Per-hypothesis quantities evaluated with the reference's own expressions
+    (src/epipolar.py:64-77), plus the winner derived by its rule (:78-81)."""
+    N = len(n0)
+    H = min(iterations, math.comb(N, 8))
+    x0 = np.hstack((n0, np.ones((N, 1))))
+    x1 = np.hstack((n1, np.ones((N, 1))))
+    idx = np.empty((H, 8), dtype=np.int32)
+    Fs = np.empty((H, 3, 3))
+    counts = np.empty(H, dtype=np.int32)
+    errsums = np.empty(H)
+    best, best_err, best_i = -1, None, -1
+    masks = None
+    for it in range(H):
+        ch = draw(N, it)
+        idx[it] = ch
+        F = epipolar.calculate_fundamental_matrix(n0[ch], n1[ch])
+        errors = np.square([(p1.T @ F) @ p0 for p0, p1 in zip(x0, x1)])
+        mask = errors < THRESH
+        e = np.sum(errors[mask])
+        c = np.count_nonzero(mask)
+        Fs[it], counts[it], errsums[it] = F, c, e
+        if c > best or (c == best and e < best_err):
+            best, best_err, best_i, masks = c, e, it, mask.copy()
+    return dict(idx=idx, F=Fs, counts=counts, errsums=errsums, best_index=np.int32(best_i),
+                best_count=np.int32(best), best_errsum=np.float64(best_err), best_mask=masks)
+
+
+def gen_ransac():
+    cases = [  # name, N, outlier fraction, seed, iterations
+        ("n8", 8, 0.0, 41, 1000),
+        ("n10", 10, 0.2, 42, 1000),
+        ("n12", 12, 0.25, 43, 1000),
+        ("n100", 100, 0.3, 44, 1000),
+        ("n256", 256, 0.3, 45, 300),
+        ("n4096", 4096, 0.3, 2, 48),
+        ("n5000", 5000, 0.7, 46, 24),
+    ]
+    for name, N, frac, seed, iters in cases:
+        d, n0, T0, n1, T1 = normalized_pair(N, frac, seed)
+        tr = ransac_trace(n0, n1, iters)
+        buf = io.StringIO()
+        logger.set_log_level("INFO")
+        with contextlib.redirect_stdout(buf):
+            F_full = epipolar.calculate_fundamental_matrix_with_ransac(n0, n1, iterations=iters)
+        logger.set_log_level("WARN")
+        # the full call must return exactly the per-hypothesis F at the derived winner
+        assert np.array_equal(F_full, tr["F"][tr["best_index"]]), name
+        np.savez_compressed(os.path.join(HERE, f"ransac_{name}.npz"), p0=n0, p1=n1,
+                            iterations=np.int32(iters), F_full=F_full, log_line=np.array(buf.getvalue()), **tr)
+        print(name, "H", len(tr["counts"]), "winner", int(tr["best_index"]), "count", int(tr["best_count"]),
+              buf.getvalue().strip())
+
+
+def gen_triangulate():
+    out = {}
+    a = np.array([[-1, -.5], [.3, .9]])
+    b = np.array([[-.9, -.45], [.35, .8]])
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    P1 = np.hstack([np.eye(3), np.array([[-1.0], [0.1], [0.05]])])
+    out["kat_P0"], out["kat_P1"], out["kat_a"], out["kat_b"] = P0, P1, a, b
+    out["kat_X"] = triangulation.triangulate_points_from_pose(P0, P1, a, b)
+    d = synth.make_pair(512, 0.3, 51)
+    K = d["K"]
+    P0 = K @ util.rotation_translation_to_pose(np.identity(3), np.zeros(3))[:3]
+    P1 = K @ util.rotation_translation_to_pose(d["R"], d["t"])[:3]
+    out["P0"], out["P1"], out["p0"], out["p1"] = P0, P1, d["pts0"], d["pts1"]
+    out["X"] = triangulation.triangulate_points_from_pose(P0, P1, d["pts0"], d["pts1"])
+    # 4x4 "camera matrices" (only rows 0..2 are read): src/triangulation.py:179-180
+    Q0 = util.rotation_translation_to_pose(np.identity(3), np.zeros(3))
+    Q1 = util.rotation_translation_to_pose(d["R"], d["t"])
+    n0 = (np.hstack([d["pts0"][:64], np.ones((64, 1))]) @ np.linalg.inv(K).T)[:, :2]
+    n1 = (np.hstack([d["pts1"][:64], np.ones((64, 1))]) @ np.linalg.inv(K).T)[:, :2]
+    out["Q0"], out["Q1"], out["q0"], out["q1"] = Q0, Q1, n0, n1
+    out["XQ"] = triangulation.triangulate_points_from_pose(Q0, Q1, n0, n1)
+    np.savez_compressed(os.path.join(HERE, "triangulate.npz"), **out)
+
+
+def pose_trace(E, p0, p1, K):
+    """Candidate enumeration exactly as src/epipolar.py:97-133, recording each candidate."""
+    u, s, v = np.linalg.svd(E)
+    w = np.asarray([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    rots = [u @ w @ v, u @ w.T @ v]
+    mult = 1 if np.linalg.det(rots[0]) > 0 else -1
+    rots = [mult * r for r in rots]
+    trans = [u[:, -1], -1 * u[:, -1]]
+    Rs, ts, counts = [], [], []
+    for R in rots:
+        for t in trans:
+            P0 = K @ util.rotation_translation_to_pose(np.identity(3), np.zeros(3))[:3]
+            P1 = K @ util.rotation_translation_to_pose(R, t)[:3]
+            X = triangulation.triangulate_points_from_pose(P0, P1, p0, p1)
+            c2 = R @ np.asarray([0, 0, 1])
+            f1 = X[:, 2] > 0
+            f2 = np.dot((X - t), c2) > 0
+            Rs.append(R); ts.append(t); counts.append(np.count_nonzero(np.multiply(f1, f2)))
+    return np.array(Rs), np.array(ts), np.array(counts, dtype=np.int32)
+
+
+def gen_pose():
+    cases = [("clean", 300, 0.0, 61), ("mixed", 400, 0.3, 62), ("heavy", 300, 0.7, 63)]
+    for name, N, frac, seed in cases:
+        d = synth.make_pair(N, frac, seed)
+        K = d["K"]
+        # F from the full front half of the path (normalise -> RANSAC -> denormalise), as custom_slam.py:96-102
+        F = custom_slam.normalize_points_and_find_fundamental_matrix(d["pts0"], d["pts1"])
+        E = epipolar.fundamental_to_essential_matrix(F, K)
+        Rs, ts, counts = pose_trace(E, d["pts0"], d["pts1"], K)
+        buf = io.StringIO()
+        logger.set_log_level("DEBUG")
+        with contextlib.redirect_stdout(buf):
+            pose, X = epipolar.calculate_pose_from_essential_matrix(E, d["pts0"], d["pts1"], K)
+        logger.set_log_level("WARN")
+        np.savez_compressed(os.path.join(HERE, f"pose_{name}.npz"), pts0=d["pts0"], pts1=d["pts1"], K=K,
+                            F=F, E=E, cand_R=Rs, cand_t=ts, cand_counts=counts, pose=pose, X=X,
+                            true_R=d["R"], true_t=d["t"], log_line=np.array(buf.getvalue()))
+        print(name, "cheirality counts", counts, buf.getvalue().strip())
+
+
+if __name__ == "__main__":
+    gen_sampler()
+    gen_normalize()
+    gen_solve()
+    gen_ransac()
+    gen_triangulate()
+    gen_pose()
+    print("python", sys.version.split()[0], "numpy", np.__version__)

@@ -1,0 +1,85 @@
+"""The C restatement (oracle/slam_oracle.c, own Jacobi SVD) against the reference's golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import fix_sign_scale, load_golden, rel_err
+from oracle import c_oracle as co
+
+
+def point_err(X, ref):
+    return float(np.max(np.abs(X - ref) / np.maximum(np.abs(ref), 1e-3)))
+
+
+@pytest.mark.parametrize("N", (8, 9, 10, 12, 21, 22, 64, 85, 86, 100, 255, 256, 257, 1000, 2048, 4096, 4097, 65535, 65536, 1 << 20))
+def test_sampler(N):
+    g = load_golden("sampler")
+    its = g[f"its_{N}"]
+    got = np.concatenate([co.sample(N, 1, it0=int(it)) for it in its])
+    assert np.array_equal(got, g[f"idx_{N}"])
+    # contiguous ranges in one call
+    assert np.array_equal(co.sample(N, 64), g[f"idx_{N}"][:64])
+
+
+@pytest.mark.parametrize("N", (6, 20, 21, 22, 300))
+def test_sampler_k6(N):
+    g = load_golden("sampler")
+    assert np.array_equal(co.sample(N, 32, k=6), g[f"k6_idx_{N}"])
+
+
+def test_normalize():
+    g = load_golden("normalize")
+    for i in range(3):
+        for j in range(2):
+            q, T = co.normalize_points(g[f"in_{i}_{j}"])
+            assert rel_err(q, g[f"pts_{i}_{j}"]) < 1e-13
+            assert rel_err(T, g[f"T_{i}_{j}"]) < 1e-13
+
+
+def test_solve():
+    g = load_golden("solve")
+    F = co.eight_point(g["kat_a"], g["kat_b"])
+    assert rel_err(fix_sign_scale(F), fix_sign_scale(g["kat_F"])) < 1e-12
+    assert abs(np.linalg.norm(F) - np.linalg.norm(g["kat_F"])) < 1e-13
+    for h in range(len(g["min_idx"])):
+        i = g["min_idx"][h]
+        F = co.eight_point(g["min_p0"][i], g["min_p1"][i])
+        assert rel_err(fix_sign_scale(F), fix_sign_scale(g["min_F"][h])) < 1e-9, h
+    for M in (9, 12, 40, 200):
+        F = co.eight_point(g[f"over_p0_{M}"], g[f"over_p1_{M}"])
+        assert rel_err(fix_sign_scale(F), fix_sign_scale(g[f"over_F_{M}"])) < 1e-9, M
+
+
+@pytest.mark.parametrize("name", ("n8", "n10", "n12", "n100", "n256", "n4096", "n5000"))
+def test_ransac(name):
+    g = load_golden("ransac_" + name)
+    r = co.ransac(g["p0"], g["p1"], g["idx"], threads=4)
+    assert np.array_equal(r["counts"], g["counts"])
+    assert np.allclose(r["errsums"], g["errsums"], rtol=1e-9, atol=1e-15)
+    if name != "n10":   # N=10 draws the same 8-subset in several orders: the winner among them is rounding noise
+        assert r["best_index"] == int(g["best_index"])
+        assert np.array_equal(r["best_mask"], g["best_mask"])
+        assert rel_err(fix_sign_scale(r["best_F"]), fix_sign_scale(g["F_full"])) < 1e-9
+    else:
+        top = np.flatnonzero(g["counts"] == g["counts"].max())
+        assert r["best_index"] in top
+
+
+def test_triangulate():
+    g = load_golden("triangulate")
+    assert point_err(co.triangulate(g["kat_P0"], g["kat_P1"], g["kat_a"], g["kat_b"]), g["kat_X"]) < 1e-10
+    assert point_err(co.triangulate(g["P0"], g["P1"], g["p0"], g["p1"]), g["X"]) < 1e-6
+    assert point_err(co.triangulate(g["Q0"], g["Q1"], g["q0"], g["q1"]), g["XQ"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ("clean", "mixed", "heavy"))
+def test_pose(name):
+    g = load_golden("pose_" + name)
+    pose, X, counts, w = co.pose_from_E(g["E"], g["K"], g["pts0"], g["pts1"], threads=4)
+    assert sorted(counts.tolist()) == sorted(g["cand_counts"].tolist())
+    assert np.allclose(pose, g["pose"], atol=1e-9)
+    assert point_err(X, g["X"]) < 1e-6
+    Rs, ts = co.pose_candidates(g["E"])
+    # same candidate set as LAPACK's (the order depends on SVD sign choices)
+    for k in range(4):
+        d = [np.abs(Rs[k] - g["cand_R"][j]).max() + np.abs(ts[k] - g["cand_t"][j]).max() for j in range(4)]
+        assert min(d) < 1e-9

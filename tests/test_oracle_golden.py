@@ -1,0 +1,109 @@
+"""The numpy restatement in oracle/ must reproduce what the reference itself produced
+(golden vectors captured by tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import fix_sign_scale, load_golden, rel_err
+from oracle import slam_oracle as so
+
+SAMPLER_NS = (8, 9, 10, 12, 21, 22, 64, 85, 86, 100, 255, 256, 257, 1000, 2048, 4096, 4097, 65535, 65536, 1 << 20)
+
+
+@pytest.mark.parametrize("N", SAMPLER_NS)
+def test_sampler_matches_cpython(N):
+    g = load_golden("sampler")
+    its = g[f"its_{N}"]
+    got = so.sample_indices(N, its)
+    assert np.array_equal(got, g[f"idx_{N}"])
+
+
+@pytest.mark.parametrize("N", (6, 20, 21, 22, 300))
+def test_sampler_k6(N):
+    g = load_golden("sampler")
+    got = so.sample_indices(N, g[f"k6_its_{N}"], k=6)
+    assert np.array_equal(got, g[f"k6_idx_{N}"])
+
+
+def test_sampler_survey_pins():
+    assert so.sample_indices(4096, [0])[0].tolist() == [2464, 1951, 1732, 2252, 382, 2443, 3679, 3301]
+    assert so.sample_indices(85, [999])[0].tolist() == [22, 0, 21, 36, 32, 82, 49, 16]
+    assert so.sample_indices(86, [999])[0].tolist() == [22, 0, 21, 36, 32, 49, 16, 6]
+
+
+def test_normalize_points():
+    g = load_golden("normalize")
+    for i in range(3):
+        for j in range(2):
+            q, T = so.normalize_points(g[f"in_{i}_{j}"])
+            assert rel_err(q, g[f"pts_{i}_{j}"]) < 1e-14
+            assert rel_err(T, g[f"T_{i}_{j}"]) < 1e-14
+
+
+def test_solve_known_answer():
+    g = load_golden("solve")
+    F = so.eight_point(g["kat_a"], g["kat_b"])
+    assert np.allclose(F, g["kat_F"], rtol=0, atol=1e-15)
+    assert abs(np.linalg.norm(F) - 0.9945512502256663) < 1e-14
+
+
+def test_solve_minimal_batch():
+    g = load_golden("solve")
+    F = so.eight_point_batch(g["min_p0"], g["min_p1"], g["min_idx"])
+    for h in range(len(F)):
+        assert rel_err(fix_sign_scale(F[h]), fix_sign_scale(g["min_F"][h])) < 1e-9
+        one = so.eight_point(g["min_p0"][g["min_idx"][h]], g["min_p1"][g["min_idx"][h]])
+        assert np.array_equal(one, g["min_F"][h])
+
+
+@pytest.mark.parametrize("M", (9, 12, 40, 200))
+def test_solve_overdetermined(M):
+    g = load_golden("solve")
+    F = so.eight_point(g[f"over_p0_{M}"], g[f"over_p1_{M}"])
+    assert np.array_equal(F, g[f"over_F_{M}"])
+
+
+@pytest.mark.parametrize("name", ("n8", "n10", "n12", "n100", "n256", "n4096", "n5000"))
+def test_ransac_trace(name):
+    g = load_golden("ransac_" + name)
+    r = so.ransac(g["p0"], g["p1"], int(g["iterations"]))
+    assert np.array_equal(r["idx"], g["idx"])
+    assert np.array_equal(r["counts"], g["counts"])
+    assert np.allclose(r["errsums"], g["errsums"], rtol=1e-9, atol=1e-15)
+    if name != "n10":
+        assert r["best_index"] == int(g["best_index"])
+        assert np.array_equal(r["best_mask"], g["best_mask"])
+        assert rel_err(fix_sign_scale(r["best_F"]), fix_sign_scale(g["F_full"])) < 1e-9
+    assert r["best_count"] == int(g["best_count"])
+
+
+def test_triangulate():
+    g = load_golden("triangulate")
+    X = so.triangulate(g["kat_P0"], g["kat_P1"], g["kat_a"], g["kat_b"])
+    assert rel_err(X, g["kat_X"]) < 1e-12
+    X = so.triangulate(g["P0"], g["P1"], g["p0"], g["p1"])
+    assert np.max(np.abs(X - g["X"]) / np.maximum(np.abs(g["X"]), 1e-3)) < 1e-7
+    X = so.triangulate(g["Q0"], g["Q1"], g["q0"], g["q1"])
+    assert np.max(np.abs(X - g["XQ"]) / np.maximum(np.abs(g["XQ"]), 1e-3)) < 1e-7
+
+
+@pytest.mark.parametrize("name", ("clean", "mixed", "heavy"))
+def test_pose_from_essential(name):
+    g = load_golden("pose_" + name)
+    E = so.fundamental_to_essential(g["F"], g["K"])
+    assert rel_err(E, g["E"]) < 1e-13
+    cands = so.pose_candidates(g["E"])
+    for k, (R, t) in enumerate(cands):
+        assert np.allclose(R, g["cand_R"][k], atol=1e-13)
+        assert np.allclose(t, g["cand_t"][k], atol=1e-13)
+    pose, X, counts = so.pose_from_essential(g["E"], g["pts0"], g["pts1"], g["K"])
+    assert np.array_equal(counts, g["cand_counts"])
+    assert np.allclose(pose, g["pose"], atol=1e-13)
+    assert np.max(np.abs(X - g["X"]) / np.maximum(np.abs(g["X"]), 1e-3)) < 1e-7
+
+
+@pytest.mark.parametrize("name", ("clean", "mixed", "heavy"))
+def test_full_pair(name):
+    g = load_golden("pose_" + name)
+    r = so.initialise_pair(g["pts0"], g["pts1"], g["K"])
+    assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(g["F"])) < 1e-8
+    assert np.array_equal(r["cheirality"], g["cand_counts"])

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the two-view initialisation hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N=1: plain; N>1: launched by torch.distributed.run)
+
+Step = one full RANSAC pass (sample -> eight-point solve -> score -> select) over one synthetic frame pair that is
+already resident in HBM: N=4096 matches, 30 % outliers, 2048 hypotheses (configuration 2 of BASELINE.json).
+With N>1 GPUs every rank runs its own frame pair (pairs are independent: no data-path collective), so the work per
+GPU is fixed ("weak" scaling) and value = hypotheses scored by all ranks / wall time of the slowest rank.
+
+One JSON line is printed by rank 0.  Besides the contract fields it carries
+  roofline      the scoring kernel against the FP64 vector-ALU peak (its bound: see DESIGN.md), durations from HIP
+                events attached to each launch on the library's stream during a second timed pass of K steps
+  cpu_baseline  the C restatement in oracle/ timed on this host's cores (rank 0, N=1 only)
+  aux           bulk triangulation + cheirality throughput (4 candidates per point) with its own roofline
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+N_MATCHES = 4096
+N_HYP = 2048
+OUTLIERS = 0.3
+FLOP_PER_EVAL = 18.0            # 8 FMA + square + masked add per (hypothesis, match)
+PEAK_FP64_VALU = 78.6           # TFLOP/s, MI355X vector FP64
+PEAK_HBM = 8000.0               # GB/s
+TRI_FLOP_PER_CAND = 2200.0      # per (point, candidate): D build, scaling, 4x4 Jacobi SVD, dehomogenise
+TRI_BYTES_PER_POINT = 88.0      # algorithmic: 2 x 32 B in (count pass + write pass) + 24 B out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--tri-points", type=int, default=1 << 24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from slam_amd import _lib, pipeline, synth
+    ctx = _lib.Context(local)
+    lib = ctx.lib
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        torch.cuda.synchronize()
+
+    # ---- inputs: one frame pair per rank, normalised as the reference's caller does, resident in HBM
+    pair = synth.make_pair(N_MATCHES, OUTLIERS, seed=2 + rank)
+    n0, _ = pipeline.normalize_points(pair["pts0"], ctx=ctx)
+    n1, _ = pipeline.normalize_points(pair["pts1"], ctx=ctx)
+    d_p0 = torch.from_numpy(n0).to(dev)
+    d_p1 = torch.from_numpy(n1).to(dev)
+    d_rec = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    d_mask = torch.zeros(N_MATCHES, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        rc = lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None, _lib.SAMPLER_CPYTHON,
+                                   _lib.SEED_BASE, 0, N_HYP, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(), d_mask.data_ptr(),
+                                   None, None, None)
+        if rc:
+            ctx.check(rc)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rec = d_rec.cpu().numpy()
+    value = world * N_HYP * args.steps / dt
+
+    # ---- roofline of the scoring kernel: per-launch durations from HIP events on the library's stream
+    ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+    ctx.check(lib.slam_profile_reset(ctx.handle))
+    barrier()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    kern = {}
+    for name, kid in (("solve", _lib.K_SOLVE), ("score", _lib.K_SCORE), ("select", _lib.K_SELECT)):
+        ms, n = C.c_double(0), C.c_int64(0)
+        ctx.check(lib.slam_profile_read(ctx.handle, kid, C.byref(ms), C.byref(n)))
+        kern[name] = (ms.value / max(n.value, 1)) * 1e3      # us per launch
+    ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+    score_us = kern["score"]
+    achieved = FLOP_PER_EVAL * N_HYP * N_MATCHES / (score_us * 1e-6) / 1e12
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_score_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "k_score", "bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU, "traffic": traffic,
+                "avg_launch_us": score_us, "flop_per_launch": FLOP_PER_EVAL * N_HYP * N_MATCHES,
+                "algorithmic_bytes_per_launch": N_MATCHES * 32 + N_HYP * 72 + N_HYP * 12,
+                "other_kernels_us": {"k_solve": kern["solve"], "k_select": kern["select"]}}
+
+    out = {"metric": "RANSAC 8-pt hypotheses scored/sec @N=4096 matches", "value": value, "unit": "hypotheses/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "config2: one synthetic frame pair per GPU, N=4096 matches, 30% outliers, "
+                                  "2048 hypotheses, CPython-compatible sampler (seed base 0x1337BEEF)",
+                      "n_matches": N_MATCHES, "hypotheses": N_HYP, "outlier_fraction": OUTLIERS,
+                      "sharding": "independent frame pairs per GPU, no collective"},
+           "residual_evals_per_sec": value * N_MATCHES,
+           "winner": {"index": int(rec[_lib.REC_INDEX]), "inliers": int(rec[_lib.REC_COUNT])},
+           "roofline": roofline}
+
+    # ---- aux: bulk triangulation + cheirality (configuration 5 shape), points resident in HBM
+    if not args.no_aux:
+        NT = args.tri_points
+        big = synth.make_pair(1 << 16, 0.0, seed=5)
+        reps = NT // (1 << 16)
+        p0 = torch.from_numpy(big["pts0"]).to(dev).repeat(reps, 1).contiguous()
+        p1 = torch.from_numpy(big["pts1"]).to(dev).repeat(reps, 1).contiguous()
+        p1 += torch.rand_like(p1) * 0.25               # make every correspondence distinct
+        E = np.ascontiguousarray(synth.essential_from_motion(big["R"], big["t"]))
+        K = np.ascontiguousarray(big["K"])
+        d_counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        d_pose = torch.zeros(16, dtype=torch.float64, device=dev)
+        d_X = torch.empty((NT, 3), dtype=torch.float64, device=dev)
+        d_win = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def tri_step():
+            ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0.data_ptr(), p1.data_ptr(), NT,
+                                                   d_counts.data_ptr()))
+            if world > 1:   # point-sharded semantics: the four counts are summed over ranks before the winner is picked
+                ctx.check(lib.slam_synchronize(ctx.handle))
+                dist.all_reduce(d_counts)
+                torch.cuda.synchronize()
+            ctx.check(lib.slam_pose_select_dev(ctx.handle, d_counts.data_ptr(), NT, d_pose.data_ptr(), d_X.data_ptr(),
+                                               d_win.data_ptr()))
+
+        tri_step()
+        barrier()
+        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+        ctx.check(lib.slam_profile_reset(ctx.handle))
+        tsteps = 5
+        t0 = time.perf_counter()
+        for _ in range(tsteps):
+            tri_step()
+        barrier()
+        tdt = time.perf_counter() - t0
+        ms, n = C.c_double(0), C.c_int64(0)
+        ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_TRIANGULATE, C.byref(ms), C.byref(n)))
+        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+        if world > 1:
+            t = torch.tensor([tdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = float(t.item())
+        tri_ms = ms.value / max(n.value, 1)
+        tf = 4 * NT * TRI_FLOP_PER_CAND / (tri_ms * 1e-3) / 1e12
+        out["aux"] = {"metric": "triangulated pts/sec (4 candidates per point, cheirality selection)",
+                      "value": world * NT * tsteps / tdt, "unit": "points/s", "points_per_gpu": NT,
+                      "candidate_triangulations_per_sec": 4 * world * NT * tsteps / tdt,
+                      "cheirality_counts": d_counts.cpu().tolist(),
+                      "roofline": {"kernel": "k_triangulate4", "bound": "valu_fp64", "achieved": tf,
+                                   "peak": PEAK_FP64_VALU, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU,
+                                   "avg_launch_ms": tri_ms,
+                                   "hbm_GBps_algorithmic": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9,
+                                   "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM}}
+        del p0, p1, d_X
+
+    # ---- CPU baseline: the C restatement on this host (rank 0, single GPU runs only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle as co
+        idx = co.sample(N_MATCHES, N_HYP)
+        co.ransac(n0, n1, idx[:64], threads=1, want_F=False, want_mask=False)      # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            o = co.ransac(n0, n1, idx, threads=1, want_F=False, want_mask=False)
+            reps += 1
+        cdt = time.perf_counter() - t0
+        ncores = min(16, os.cpu_count() or 1)
+        t1 = time.perf_counter()
+        co.ransac(n0, n1, idx, threads=ncores, want_F=False, want_mask=False)
+        mdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": reps * N_HYP / cdt, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+                               "sample": f"the full step workload (N=4096, H=2048, same indices) repeated {reps}x over "
+                                         f"{cdt:.1f} s on one core, oracle/slam_oracle.c (-O3, no FMA contraction)",
+                               "all_cores": {"value": N_HYP / mdt, "cores": ncores},
+                               "winner_matches_gpu": bool(o["best_index"] == int(rec[_lib.REC_INDEX])),
+                               "reference_python_measured_in_survey": {"value": 80.0, "unit": "hypotheses/s", "cores": 1}}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * slam_amd — C ABI of the MI355X-native two-view initialisation path
+ * (8-point fundamental-matrix RANSAC + linear DLT triangulation with cheirality selection).
+ *
+ * The reference (patosai/slam) has no FFI layer: its boundary is the Python module surface of
+ * src/epipolar.py and src/triangulation.py.  Each entry point below names the reference function it
+ * replaces; slam_amd/epipolar.py and slam_amd/triangulation.py bind them with ctypes.
+ *
+ * Conventions
+ *  - All matrices are row-major float64.  Point arrays are (N,2) row-major float64, exactly numpy's layout.
+ *  - "host" entry points take host pointers, copy in/out and return after the work has finished.
+ *  - "_dev" entry points take DEVICE pointers, enqueue work on the context's stream and return without
+ *    synchronising; the caller owns all buffers.  They allocate only when a size exceeds what the context
+ *    has seen before.
+ *  - Return value: 0 on success, a negative SLAM_E* code otherwise; slam_last_error() gives the text.
+ *  - A context is bound to one GPU and one stream; use one context per thread.
+ *  - There is no CPU implementation behind this ABI: slam_create fails when no gfx950 device is usable.
+ */
+#ifndef SLAM_AMD_H
+#define SLAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slam_ctx slam_ctx;
+
+enum {
+    SLAM_OK = 0,
+    SLAM_EINVAL = -1,      /* bad argument (NULL pointer, N < 8, H < 1, ...): the reference asserts here */
+    SLAM_EHIP = -2,        /* a HIP runtime call failed */
+    SLAM_ENOMEM = -3,      /* device or host allocation failed */
+    SLAM_ESAMPLER = -4,    /* the sampler ran out of pre-generated random words (see slam_sample8_cpython) */
+    SLAM_ENODEVICE = -5    /* no usable GPU */
+};
+
+/* the reference's constants: src/epipolar.py:54 (iterations), :63 (threshold), :70 (seed base) */
+#define SLAM_DEFAULT_ITERATIONS 1000
+#define SLAM_DEFAULT_THRESHOLD 0.005
+#define SLAM_SEED_BASE 0x1337BEEFull
+
+/* sampler kinds for the RANSAC entry points */
+#define SLAM_SAMPLER_CPYTHON 0 /* random.seed(seed + it); random.sample(range(N), 8) : src/epipolar.py:70-71 */
+#define SLAM_SAMPLER_COUNTER 1 /* Philox4x32-10 keyed by (seed, it): any GPU can draw any hypothesis */
+
+/* record written by the RANSAC entry points: 12 float64 values */
+#define SLAM_REC_COUNT 0  /* inlier count of the winner (integer value) */
+#define SLAM_REC_ERRSUM 1 /* sum of its inlier residuals */
+#define SLAM_REC_INDEX 2  /* its iteration index, it0 + h (integer value) */
+#define SLAM_REC_F 3      /* its 3x3 F, row-major, entries 3..11 */
+#define SLAM_REC_LEN 12
+
+/* ---- lifecycle -------------------------------------------------------------------------------- */
+int slam_create(int device, slam_ctx** out);
+void slam_destroy(slam_ctx* ctx);
+const char* slam_last_error(const slam_ctx* ctx); /* ctx may be NULL: text of the last slam_create failure */
+/* use the caller's HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it */
+int slam_set_stream(slam_ctx* ctx, void* hip_stream);
+int slam_synchronize(slam_ctx* ctx);
+
+/* ---- sampler: src/epipolar.py:62,69-71 ---------------------------------------------------------- */
+/* number of hypotheses the reference runs: min(iterations, C(N, 8))   (src/epipolar.py:69) */
+int64_t slam_num_hypotheses(int64_t n_points, int64_t iterations);
+/* idx[h*k + j] = j-th index of the sample drawn in iteration it0 + h.  kind = SLAM_SAMPLER_*.
+ * k is 8 for the fundamental-matrix loop and 6 for the tracking loop (src/triangulation.py:155).
+ * The draw runs on the GPU from a table of MT19937 output words kept per context. */
+int slam_sample_indices(slam_ctx* ctx, int kind, uint64_t seed, int64_t it0, int H, int N, int k, int32_t* idx);
+
+/* ---- eight-point solve: src/epipolar.py:18-51  calculate_fundamental_matrix ---------------------- */
+/* p0 = img0_points, p1 = img1_points, (M,2) each, M >= 8.  F: 9 values, rank 2, in the coordinates of the
+ * input points, sign arbitrary (as the reference's). */
+int slam_eightpoint(slam_ctx* ctx, const double* p0, const double* p1, int M, double* F);
+
+/* ---- RANSAC: src/epipolar.py:54-84  calculate_fundamental_matrix_with_ransac --------------------- */
+/* Scores H hypotheses (iterations it0 .. it0+H-1) on N matches and selects by the reference's rule
+ * (more inliers, then smaller inlier-error sum, then earlier iteration: src/epipolar.py:78-81).
+ * idx: H*8 pre-drawn indices, or NULL to draw them with `sampler`/`seed`.
+ * Outputs (any may be NULL except record): record[SLAM_REC_LEN]; mask[N] (1 = inlier of the winner);
+ * counts[H], errsums[H], F_all[H*9] per hypothesis. */
+int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, int N, const int32_t* idx, int sampler,
+                  uint64_t seed, int64_t it0, int H, double threshold, double* record, uint8_t* mask,
+                  int32_t* counts, double* errsums, double* F_all);
+/* same with device pointers, asynchronous on the context's stream */
+int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
+                      int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
+                      uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all);
+/* Merge per-rank winner records (host memory, n_records * SLAM_REC_LEN) by the same rule; used after the
+ * all-gather of a hypothesis-sharded run.  Writes the winning record to out and returns its position. */
+int slam_merge_records(const double* records, int n_records, double* out);
+
+/* ---- caller-side glue of custom_slam.py --------------------------------------------------------- */
+/* custom_slam.py:85-93 normalize_points: out (N,2), T 3x3 (with the reference's s where 1/s is expected) */
+int slam_normalize_points(slam_ctx* ctx, const double* p, int N, double* out, double* T);
+/* src/epipolar.py:87-92 fundamental_to_essential_matrix: E = K^T F K / ||.||_F */
+int slam_fundamental_to_essential(slam_ctx* ctx, const double* F, const double* K, double* E);
+
+/* ---- triangulation: src/triangulation.py:8-75  triangulate_points_from_pose --------------------- */
+/* P0, P1: first three rows (3x4, 12 values) of the two camera matrices; X: (N,3). */
+int slam_triangulate(slam_ctx* ctx, const double* P0, const double* P1, const double* p0, const double* p1,
+                     int64_t N, double* X);
+int slam_triangulate_dev(slam_ctx* ctx, const double* P0_host, const double* P1_host, const double* d_p0,
+                         const double* d_p1, int64_t N, double* d_X);
+
+/* ---- pose recovery: src/epipolar.py:95-136  calculate_pose_from_essential_matrix ---------------- */
+/* Triangulates all N matches for the four (R,t) decompositions of E and keeps the one with most points in
+ * front of both cameras (strict >, candidates in the order (R0,t0),(R0,t1),(R1,t0),(R1,t1)).
+ * pose: 4x4; X: (N,3) points of the winner; counts4: in-front counts per candidate; winner: its position.
+ * The ORDER of the candidates follows this library's own SVD sign choices, not LAPACK's. */
+int slam_pose_from_E(slam_ctx* ctx, const double* E, const double* K, const double* p0, const double* p1,
+                     int64_t N, double* pose, double* X, int32_t* counts4, int32_t* winner);
+/* Two-phase device form for point-sharded runs: phase 1 triangulates this rank's points for all four
+ * candidates and leaves the four in-front counts in d_counts4 (int64, to be summed across ranks by the
+ * caller); phase 2 picks the winner from the (summed) counts and writes pose (16) and this rank's X. */
+int slam_pose_candidates_dev(slam_ctx* ctx, const double* E_host, const double* K_host, const double* d_p0,
+                             const double* d_p1, int64_t N, int64_t* d_counts4);
+int slam_pose_select_dev(slam_ctx* ctx, const int64_t* d_counts4, int64_t N, double* d_pose, double* d_X,
+                         int32_t* d_winner);
+
+/* ---- whole pair: custom_slam.py:96-115 (normalise, RANSAC, denormalise, F->E, pose, z>0 mask) ----- */
+/* pts0, pts1: pixel matches (N,2).  Outputs: F (denormalised), E, pose 4x4, X (N,3), good[N] (X_z > 0),
+ * record (as slam_ransac_f), counts4, winner.  One upload and one download per call. */
+int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* pts1, int N, const double* K, int iterations,
+                   double* F, double* E, double* pose, double* X, uint8_t* good, double* record,
+                   int32_t* counts4, int32_t* winner);
+
+/* ---- kernel timing for benchmarks ---------------------------------------------------------------- */
+#define SLAM_K_SOLVE 0
+#define SLAM_K_SCORE 1
+#define SLAM_K_SELECT 2
+#define SLAM_K_TRIANGULATE 3
+#define SLAM_K_COUNT 4
+/* When enabled, every launch of the kernels above is bracketed by HIP events on the context's stream. */
+int slam_profile_enable(slam_ctx* ctx, int on);
+/* Synchronises, then returns total milliseconds and number of launches recorded for `kernel` since the last reset. */
+int slam_profile_read(slam_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
+int slam_profile_reset(slam_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_AMD_H */

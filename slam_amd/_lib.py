@@ -1,0 +1,125 @@
+"""ctypes binding of libslam_amd.so (C ABI: include/slam_amd.h).
+
+There is no fallback: if the shared library is missing or no gfx950 GPU is usable, the first call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libslam_amd.so")
+
+REC_COUNT, REC_ERRSUM, REC_INDEX, REC_F, REC_LEN = 0, 1, 2, 3, 12
+SAMPLER_CPYTHON, SAMPLER_COUNTER = 0, 1
+SEED_BASE = 0x1337BEEF
+DEFAULT_THRESHOLD = 0.005
+K_SOLVE, K_SCORE, K_SELECT, K_TRIANGULATE = 0, 1, 2, 3
+
+# every symbol include/slam_amd.h declares, with its ctypes signature
+_vp, _i32, _i64, _u64, _f64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_int
+SIGNATURES = {
+    "slam_create": (_int, [_int, C.POINTER(_vp)]),
+    "slam_destroy": (None, [_vp]),
+    "slam_last_error": (C.c_char_p, [_vp]),
+    "slam_set_stream": (_int, [_vp, _vp]),
+    "slam_synchronize": (_int, [_vp]),
+    "slam_num_hypotheses": (_i64, [_i64, _i64]),
+    "slam_sample_indices": (_int, [_vp, _int, _u64, _i64, _int, _int, _int, _vp]),
+    "slam_eightpoint": (_int, [_vp, _vp, _vp, _int, _vp]),
+    "slam_ransac_f": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "slam_ransac_f_dev": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "slam_merge_records": (_int, [_vp, _int, _vp]),
+    "slam_normalize_points": (_int, [_vp, _vp, _int, _vp, _vp]),
+    "slam_fundamental_to_essential": (_int, [_vp, _vp, _vp, _vp]),
+    "slam_triangulate": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "slam_triangulate_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "slam_pose_from_E": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "slam_pose_candidates_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "slam_pose_select_dev": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "slam_init_pair": (_int, [_vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slam_profile_enable": (_int, [_vp, _int]),
+    "slam_profile_read": (_int, [_vp, _int, C.POINTER(_f64), C.POINTER(_i64)]),
+    "slam_profile_reset": (_int, [_vp]),
+}
+
+
+class SlamError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen the library and declare the signatures (does not touch the GPU)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise SlamError(f"{LIB_PATH} is missing: build it with `make -C slam_amd/csrc` "
+                                "(there is no CPU fallback)")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+class Context:
+    """One GPU, one stream.  Not thread-safe; use one per thread."""
+
+    def __init__(self, device=None):
+        self.lib = load()
+        if device is None:
+            device = int(os.environ.get("SLAM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = _vp()
+        rc = self.lib.slam_create(int(device), C.byref(h))
+        if rc != 0:
+            raise SlamError(f"slam_create(device={device}) failed ({rc}): "
+                            f"{self.lib.slam_last_error(None).decode()}")
+        self.handle = h
+        self.device = int(device)
+
+    def check(self, rc):
+        if rc < 0:
+            msg = self.lib.slam_last_error(self.handle).decode()
+            if rc == -1:
+                # the reference guards these preconditions with `assert`
+                raise AssertionError(msg)
+            raise SlamError(f"libslam_amd error {rc}: {msg}")
+        return rc
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.slam_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)

@@ -1,0 +1,117 @@
+// Context, error handling and scratch management shared by the translation units of libslam_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/slam_amd.h"
+
+#define SLAM_RAW_WORDS 96  // MT19937 output words kept per iteration for the CPython-compatible sampler
+
+struct slam_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct slam_prof {
+    static const int kMax = 4096;
+    hipEvent_t start[kMax];
+    hipEvent_t stop[kMax];
+    int kernel[kMax];
+    int used = 0;
+    bool created = false;
+    double total_ms[SLAM_K_COUNT] = {0, 0, 0, 0};
+    int64_t launches[SLAM_K_COUNT] = {0, 0, 0, 0};
+};
+
+struct slam_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+
+    // device scratch (grown on demand, never shrunk)
+    slam_buf pts;       // staged (N,2)+(N,2) points of the host entry points
+    slam_buf idx;       // H*8 int32
+    slam_buf F;         // H*9 f64
+    slam_buf counts;    // H int32
+    slam_buf errsums;   // H f64
+    slam_buf mask;      // N u8
+    slam_buf record;    // SLAM_REC_LEN f64 + flags
+    slam_buf raw;       // MT19937 words [raw_n][SLAM_RAW_WORDS]
+    slam_buf X4;        // 4 candidate planes of N*3 f64
+    slam_buf X;         // N*3 f64 staging
+    slam_buf small;     // small matrices: candidates, poses, T, E ...
+    slam_buf flags;     // int32[4] error flags written by kernels
+    uint64_t raw_seed = 0;
+    int64_t raw_it0 = 0, raw_n = 0;
+
+    // pinned host staging for small results
+    double* h_small = nullptr;  // 256 doubles
+    int32_t* h_flags = nullptr;
+
+    bool profiling = false;
+    slam_prof prof;
+};
+
+#define SLAM_HIP(ctx, call)                                                                               \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                                 \
+            return SLAM_EHIP;                                                                             \
+        }                                                                                                 \
+    } while (0)
+
+#define SLAM_REQUIRE(ctx, cond, msg)                                                    \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            snprintf((ctx)->err, sizeof((ctx)->err), "invalid argument: %s", msg);      \
+            return SLAM_EINVAL;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define SLAM_TRY(call)            \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != SLAM_OK) return rc_; \
+    } while (0)
+
+// make sure b holds at least `bytes`; contents are NOT preserved
+static inline int slam_reserve(slam_ctx* ctx, slam_buf& b, size_t bytes) {
+    if (bytes <= b.cap) return SLAM_OK;
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    // a buffer may still be in use by work queued on the stream
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.p) SLAM_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return SLAM_ENOMEM;
+    }
+    b.cap = want;
+    return SLAM_OK;
+}
+
+// Launch on the context's stream.  With profiling on, the launch carries a start/stop event pair whose
+// timestamps are those of the dispatch itself, so the elapsed time is the kernel's own duration.
+int slam_prof_slot(slam_ctx* ctx, int kernel);  // next free event pair, or -1
+
+template <typename... KArgs, typename... Args>
+static inline int slam_launch(slam_ctx* ctx, int kernel_id, void (*kernel)(KArgs...), dim3 grid, dim3 block,
+                              unsigned shmem, Args... args) {
+    int slot = (ctx->profiling && kernel_id >= 0) ? slam_prof_slot(ctx, kernel_id) : -1;
+    if (slot >= 0)
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, ctx->prof.start[slot], ctx->prof.stop[slot], 0,
+                              static_cast<KArgs>(args)...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, static_cast<KArgs>(args)...);
+    SLAM_HIP(ctx, hipGetLastError());
+    return SLAM_OK;
+}

@@ -1,0 +1,437 @@
+// Triangulation, pose recovery and the small per-pair matrix steps, gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "linalg.h"
+
+namespace slamk {
+
+// Layout of the per-context "pose work" block (float64 words) shared by the kernels below.
+enum {
+    PW_P0 = 0,            // 12: K [I|0]
+    PW_CAND = 12,         // 4 candidates x PW_CAND_LEN
+    PW_CAND_P1 = 0,       //   12: K [R^T | -R^T t]
+    PW_CAND_T = 12,       //   3 : t
+    PW_CAND_CZ = 15,      //   3 : R (0,0,1)^T = third column of R
+    PW_CAND_POSE = 18,    //   16: [[R^T, -R^T t],[0,0,0,1]]
+    PW_CAND_LEN = 34,
+    PW_E = 12 + 4 * 34,   // 9
+    PW_F = PW_E + 9,      // 9 (denormalised F of the pair pipeline)
+    PW_T0 = PW_F + 9,     // 9
+    PW_T1 = PW_T0 + 9,    // 9
+    PW_K = PW_T1 + 9,     // 9
+    PW_LEN = PW_K + 9 + 3
+};
+
+// ------------------------------------------------------------------------------------------------
+// One DLT triangulation   (reference: src/triangulation.py:50-73)
+//   D rows: -P0[1] + v P0[2];  P0[0] - u P0[2];  -P1[1] + v' P1[2];  P1[0] - u' P1[2]
+//   m_i = max_j |D_ij| ; D' = D diag(1/m) (column j divided by m_j) ; y = right singular vector of the smallest
+//   singular value of D' ; Y = diag(m) y ; X = Y[0..2] / Y[3]
+// P0, P1 are wave-uniform pointers (scalar loads).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, const double* __restrict__ P1, double u0,
+                                                double v0, double u1, double v1, double (&X)[3]) {
+    double D[4][4], V[4][4], m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        D[0][j] = fma(v0, P0[8 + j], -P0[4 + j]);
+        D[1][j] = fma(-u0, P0[8 + j], P0[j]);
+        D[2][j] = fma(v1, P1[8 + j], -P1[4 + j]);
+        D[3][j] = fma(-u1, P1[8 + j], P1[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = fmax(fmax(fabs(D[i][0]), fabs(D[i][1])), fmax(fabs(D[i][2]), fabs(D[i][3])));
+    double im[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) im[j] = 1.0 / m[j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) D[i][j] *= im[j];
+    jacobi_svd<4, 4>(D, V, 30);
+    double n2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n2[j] = D[0][j] * D[0][j] + D[1][j] * D[1][j] + D[2][j] * D[2][j] + D[3][j] * D[3][j];
+    int least = 0;
+    double best = n2[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const bool lt = n2[j] < best;
+        best = lt ? n2[j] : best;
+        least = lt ? j : least;
+    }
+    double Y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double y = least == 0 ? V[i][0] : (least == 1 ? V[i][1] : (least == 2 ? V[i][2] : V[i][3]));
+        Y[i] = m[i] * y;
+    }
+    X[0] = Y[0] / Y[3];
+    X[1] = Y[1] / Y[3];
+    X[2] = Y[2] / Y[3];
+}
+
+struct Cams {  // kernel argument: the first three rows of both camera matrices
+    double P0[12];
+    double P1[12];
+};
+struct Mat3x2 {  // kernel argument: two 3x3 matrices
+    double A[9];
+    double B[9];
+};
+
+// K4a: plain triangulation with one camera pair (slam_triangulate)
+__global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* __restrict__ p0,
+                                                     const double2* __restrict__ p1, int64_t N,
+                                                     double* __restrict__ Xout) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double2 a = p0[i], b = p1[i];
+    double X[3];
+    triangulate_one(cams.P0, cams.P1, a.x, a.y, b.x, b.y, X);
+    Xout[3 * i + 0] = X[0];
+    Xout[3 * i + 1] = X[1];
+    Xout[3 * i + 2] = X[2];
+}
+
+// K4b: the four (R,t) candidates of one E   (reference: src/epipolar.py:113-127)
+//   in front of camera 1: X_z > 0 ; in front of camera 2: (X - t) . (R e_z) > 0 ; count points passing both.
+// Every candidate's points go to its own plane X4[c][N][3]; counts4 (int64) must be zero on entry.
+__global__ __launch_bounds__(256) void k_triangulate4(const double* __restrict__ pw, const double2* __restrict__ p0,
+                                                      const double2* __restrict__ p1, int64_t N,
+                                                      double* __restrict__ X4,
+                                                      unsigned long long* __restrict__ counts4) {
+    __shared__ int s_cnt[4][4];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = i < N;
+    const int64_t ii = live ? i : N - 1;
+    const double2 a = p0[ii], b = p1[ii];
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        const double* __restrict__ cand = pw + PW_CAND + c * PW_CAND_LEN;
+        double X[3];
+        triangulate_one(pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
+        const double tx = cand[PW_CAND_T], ty = cand[PW_CAND_T + 1], tz = cand[PW_CAND_T + 2];
+        const double cx = cand[PW_CAND_CZ], cy = cand[PW_CAND_CZ + 1], cz = cand[PW_CAND_CZ + 2];
+        const bool f1 = X[2] > 0.0;
+        const bool f2 = ((X[0] - tx) * cx + (X[1] - ty) * cy + (X[2] - tz) * cz) > 0.0;
+        const int n = __popcll(__ballot(live && f1 && f2));
+        if ((tid & 63) == 0) s_cnt[c][tid >> 6] = n;
+        if (live) {
+            double* o = X4 + ((size_t)c * (size_t)N + (size_t)i) * 3;
+            o[0] = X[0];
+            o[1] = X[1];
+            o[2] = X[2];
+        }
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int n = s_cnt[tid][0] + s_cnt[tid][1] + s_cnt[tid][2] + s_cnt[tid][3];
+        if (n) atomicAdd(&counts4[tid], (unsigned long long)n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Candidate enumeration   (reference: src/epipolar.py:97-107,117-118; src/util.py:30-37)
+//   u,s,vt = svd(E); R in {u W vt, u W^T vt} * sign(det(u W vt)); t in {u[:,2], -u[:,2]}
+//   pose(R,t) = [[R^T, -R^T t],[0,0,0,1]]; P1 = K pose[:3]; P0 = K [I|0]
+// The order of the two R (and of the two t) depends on the sign choices of the SVD routine; this one
+// orders by its own Jacobi SVD with singular values sorted descending and u3 = u1 x u2.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(bool doit, double& x, double& y) {
+    const double t = x;
+    x = doit ? y : x;
+    y = doit ? t : y;
+}
+
+__device__ inline void pose_prepare(const double* __restrict__ E, const double* __restrict__ K, double* __restrict__ pw) {
+    double B[3][3], V[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) B[r][c] = E[3 * r + c];
+    jacobi_svd<3, 3>(B, V, 30);
+    double n2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];
+    // sort columns by descending norm (3-element network: (0,1) (1,2) (0,1))
+#define SLAM_CSWAP_COL(p, q)                                                  \
+    {                                                                         \
+        const bool sw = n2[q] > n2[p];                                        \
+        cswap(sw, n2[p], n2[q]);                                              \
+        for (int r_ = 0; r_ < 3; ++r_) { cswap(sw, B[r_][p], B[r_][q]); cswap(sw, V[r_][p], V[r_][q]); } \
+    }
+    SLAM_CSWAP_COL(0, 1)
+    SLAM_CSWAP_COL(1, 2)
+    SLAM_CSWAP_COL(0, 1)
+#undef SLAM_CSWAP_COL
+    double U[3][3];
+    const double i0 = 1.0 / sqrt(n2[0]), i1 = 1.0 / sqrt(n2[1]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { U[r][0] = B[r][0] * i0; U[r][1] = B[r][1] * i1; }
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    // U W = [u2, -u1, u3] ; U W^T = [-u2, u1, u3]   (W = [[0,-1,0],[1,0,0],[0,0,1]])
+    double R[2][3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double x = U[r][1] * V[c][0] - U[r][0] * V[c][1];
+            const double z = U[r][2] * V[c][2];
+            R[0][r][c] = x + z;
+            R[1][r][c] = -x + z;
+        }
+    const double det = R[0][0][0] * (R[0][1][1] * R[0][2][2] - R[0][1][2] * R[0][2][1]) -
+                       R[0][0][1] * (R[0][1][0] * R[0][2][2] - R[0][1][2] * R[0][2][0]) +
+                       R[0][0][2] * (R[0][1][0] * R[0][2][1] - R[0][1][1] * R[0][2][0]);
+    const double mult = det > 0.0 ? 1.0 : -1.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pw[PW_P0 + 4 * r + c] = K[3 * r + c]; }
+    pw[PW_P0 + 3] = 0.0; pw[PW_P0 + 7] = 0.0; pw[PW_P0 + 11] = 0.0;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int ri = ci >> 1;
+        const double ts = (ci & 1) ? -1.0 : 1.0;
+        double* __restrict__ cand = pw + PW_CAND + ci * PW_CAND_LEN;
+        double t[3], pose[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[r] = ts * U[r][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pose[r][c] = mult * R[ri][c][r];  // R^T
+                s += pose[r][c] * t[c];
+            }
+            pose[r][3] = -s;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                cand[PW_CAND_P1 + 4 * r + c] = K[3 * r] * pose[0][c] + K[3 * r + 1] * pose[1][c] + K[3 * r + 2] * pose[2][c];
+                cand[PW_CAND_POSE + 4 * r + c] = pose[r][c];
+            }
+        cand[PW_CAND_POSE + 12] = 0.0; cand[PW_CAND_POSE + 13] = 0.0; cand[PW_CAND_POSE + 14] = 0.0;
+        cand[PW_CAND_POSE + 15] = 1.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cand[PW_CAND_T + r] = t[r]; cand[PW_CAND_CZ + r] = mult * R[ri][r][2]; }
+    }
+}
+
+// F -> E   (reference: src/epipolar.py:87-92):  E = K^T F K / ||K^T F K||_F
+__device__ inline void f_to_e(const double* __restrict__ F, const double* __restrict__ K, double* __restrict__ E) {
+    double T[3][3], G[3][3], n2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[r][c] = K[r] * F[c] + K[3 + r] * F[3 + c] + K[6 + r] * F[6 + c];  // K^T F
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            G[r][c] = T[r][0] * K[c] + T[r][1] * K[3 + c] + T[r][2] * K[6 + c];
+            n2 += G[r][c] * G[r][c];
+        }
+    const double nrm = sqrt(n2);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) E[3 * r + c] = G[r][c] / nrm;
+}
+
+// zero the candidate counters and build the candidates from E (ek.A) and K (ek.B)
+__global__ __launch_bounds__(64) void k_pose_prepare(Mat3x2 ek, double* __restrict__ pw,
+                                                     unsigned long long* __restrict__ counts4) {
+    if (threadIdx.x < 4) counts4[threadIdx.x] = 0ull;
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < 9; ++i) { pw[PW_E + i] = ek.A[i]; pw[PW_K + i] = ek.B[i]; }
+    pose_prepare(ek.A, ek.B, pw);
+}
+
+// pair pipeline middle step: denormalise the RANSAC winner (custom_slam.py:101: T1^T F T0), F -> E, candidates
+__global__ __launch_bounds__(64) void k_pair_mid(Mat3x2 kk /* A = K */, const double* __restrict__ record,
+                                                 double* __restrict__ pw, unsigned long long* __restrict__ counts4) {
+    if (threadIdx.x < 4) counts4[threadIdx.x] = 0ull;
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < 9; ++i) pw[PW_K + i] = kk.A[i];
+    const double* Fn = record + SLAM_REC_F;
+    const double* T0 = pw + PW_T0;
+    const double* T1 = pw + PW_T1;
+    double A[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A[r][c] = T1[r] * Fn[c] + T1[3 + r] * Fn[3 + c] + T1[6 + r] * Fn[6 + c];  // T1^T F
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pw[PW_F + 3 * r + c] = A[r][0] * T0[c] + A[r][1] * T0[3 + c] + A[r][2] * T0[6 + c];
+    double E[9];
+    f_to_e(pw + PW_F, kk.A, E);
+    for (int i = 0; i < 9; ++i) pw[PW_E + i] = E[i];
+    pose_prepare(E, kk.A, pw);
+}
+
+__global__ __launch_bounds__(64) void k_f_to_e(Mat3x2 fk /* A = F, B = K */, double* __restrict__ Eout) {
+    if (threadIdx.x == 0) f_to_e(fk.A, fk.B, Eout);
+}
+
+// winner = first candidate with the strictly largest count   (reference: src/epipolar.py:129-133)
+__global__ __launch_bounds__(64) void k_pose_select(const double* __restrict__ pw,
+                                                    const unsigned long long* __restrict__ counts4,
+                                                    double* __restrict__ pose, int32_t* __restrict__ winner) {
+    __shared__ int s_w;
+    if (threadIdx.x == 0) {
+        long long best = -1;
+        int w = 0;
+        for (int c = 0; c < 4; ++c) {
+            const long long n = (long long)counts4[c];
+            if (n > best) { best = n; w = c; }
+        }
+        s_w = w;
+        *winner = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) pose[threadIdx.x] = pw[PW_CAND + s_w * PW_CAND_LEN + PW_CAND_POSE + threadIdx.x];
+}
+
+// copy the winner's plane to the output and optionally flag X_z > 0 (custom_slam.py:114)
+__global__ __launch_bounds__(256) void k_emit_points(const double* __restrict__ X4, const int32_t* __restrict__ winner,
+                                                     int64_t N, double* __restrict__ X, uint8_t* __restrict__ good) {
+    const double* src = X4 + (size_t)(*winner) * (size_t)N * 3;
+    const int64_t total = N * 3;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const double v = src[e];
+        X[e] = v;
+        if (good && (e % 3) == 2) good[e / 3] = v > 0.0 ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalize_points   (reference: custom_slam.py:85-93)
+//   avg = mean(p); s = mean(||p - avg||) / sqrt(2); out = (p - avg)/s; T = [[s,0,-s ax],[0,s,-s ay],[0,0,1]]
+// Single workgroup, fixed-order reductions.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_1024(double v, double* s_red) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += s_red[w];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void k_normalize(const double2* __restrict__ p, int N, double2* __restrict__ out,
+                                                    double* __restrict__ T) {
+    __shared__ double s_red[16];
+    const int tid = threadIdx.x;
+    double sx = 0.0, sy = 0.0;
+    for (int i = tid; i < N; i += 1024) { const double2 v = p[i]; sx += v.x; sy += v.y; }
+    const double ax = block_sum_1024(sx, s_red) / (double)N;
+    const double ay = block_sum_1024(sy, s_red) / (double)N;
+    double sd = 0.0;
+    for (int i = tid; i < N; i += 1024) {
+        const double2 v = p[i];
+        const double dx = v.x - ax, dy = v.y - ay;
+        sd += sqrt(dx * dx + dy * dy);
+    }
+    const double s = (block_sum_1024(sd, s_red) / (double)N) / sqrt(2.0);
+    for (int i = tid; i < N; i += 1024) {
+        const double2 v = p[i];
+        out[i] = make_double2((v.x - ax) / s, (v.y - ay) / s);
+    }
+    if (tid == 0) {
+        T[0] = s;   T[1] = 0.0; T[2] = -1.0 * s * ax;
+        T[3] = 0.0; T[4] = s;   T[5] = -1.0 * s * ay;
+        T[6] = 0.0; T[7] = 0.0; T[8] = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Over-determined eight-point solve, M > 8 rows   (reference: src/epipolar.py:37-51 with len(points) > 8)
+// The least right singular vector of the M x 9 design matrix equals that of its 9 x 9 triangular factor R:
+// rows are folded into R with Givens rotations, then R goes through a one-sided Jacobi SVD.  One lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_eightpoint_general(const double2* __restrict__ p0, const double2* __restrict__ p1,
+                                                           int M, double* __restrict__ Fout) {
+    __shared__ double R[9][9];
+    __shared__ double V[9][9];
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) { R[i][j] = 0.0; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int i = 0; i < M; ++i) {
+        const double2 a = p0[i], b = p1[i];
+        double row[9] = {b.x * a.x, b.x * a.y, b.x, b.y * a.x, b.y * a.y, b.y, a.x, a.y, 1.0};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double x = R[k][k], y = row[k];
+            if (y != 0.0) {
+                const double r = sqrt(x * x + y * y);
+                const double c = x / r, s = y / r;
+                R[k][k] = r;
+#pragma unroll
+                for (int j = k + 1; j < 9; ++j) {
+                    const double t1 = R[k][j], t2 = row[j];
+                    R[k][j] = c * t1 + s * t2;
+                    row[j] = c * t2 - s * t1;
+                }
+            }
+        }
+    }
+    double fro2 = 0.0;
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) fro2 += R[i][j] * R[i][j];
+    const double floor2 = fro2 * 1e-32;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                double a = 0.0, b = 0.0, c = 0.0;
+                for (int i = 0; i < 9; ++i) {
+                    a = fma(R[i][p], R[i][p], a);
+                    b = fma(R[i][q], R[i][q], b);
+                    c = fma(R[i][p], R[i][q], c);
+                }
+                if (!(a > floor2 && b > floor2 && c * c > 1e-30 * (a * b))) continue;
+                rotated = true;
+                double cs, sn;
+                jacobi_angle(a, b, c, cs, sn);
+                for (int i = 0; i < 9; ++i) {
+                    const double x = R[i][p], y = R[i][q];
+                    R[i][p] = fma(cs, x, -sn * y);
+                    R[i][q] = fma(sn, x, cs * y);
+                    const double vx = V[i][p], vy = V[i][q];
+                    V[i][p] = fma(cs, vx, -sn * vy);
+                    V[i][q] = fma(sn, vx, cs * vy);
+                }
+            }
+        if (!rotated) break;
+    }
+    int least = 0;
+    double best = 1e300;
+    for (int j = 0; j < 9; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < 9; ++i) s += R[i][j] * R[i][j];
+        if (s < best) { best = s; least = j; }
+    }
+    double f[9], F[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) f[i] = V[i][least];
+    rank2_project(f, F);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Fout[i] = F[i];
+}
+
+}  // namespace slamk

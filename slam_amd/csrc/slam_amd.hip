@@ -1,0 +1,634 @@
+// libslam_amd.so — host side of the C ABI declared in include/slam_amd.h (gfx950 only).
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "ctx.h"
+#include "kernels_ransac.h"
+#include "kernels_tri.h"
+
+using namespace slamk;
+
+static char g_create_err[512] = "";
+
+// ================================================================================================
+// lifecycle
+// ================================================================================================
+extern "C" int slam_create(int device, slam_ctx** out) {
+    if (!out) return SLAM_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(g_create_err, sizeof g_create_err, "no HIP device available (%s)", hipGetErrorString(e));
+        return SLAM_ENODEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof g_create_err, "device %d out of range (0..%d)", device, ndev - 1);
+        return SLAM_EINVAL;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        snprintf(g_create_err, sizeof g_create_err, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return SLAM_EHIP;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_create_err, sizeof g_create_err, "device %d is %s; this library carries gfx950 code only", device,
+                 prop.gcnArchName);
+        return SLAM_ENODEVICE;
+    }
+    slam_ctx* ctx = new (std::nothrow) slam_ctx();
+    if (!ctx) return SLAM_ENOMEM;
+    ctx->device = device;
+    auto fail = [&](const char* what, hipError_t err) {
+        snprintf(g_create_err, sizeof g_create_err, "%s: %s", what, hipGetErrorString(err));
+        delete ctx;
+        return SLAM_EHIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return fail("hipStreamCreate", e);
+    ctx->stream = ctx->own_stream;
+    if ((e = hipHostMalloc((void**)&ctx->h_small, 256 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
+        return fail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&ctx->h_flags, 16 * sizeof(int32_t), hipHostMallocDefault)) != hipSuccess)
+        return fail("hipHostMalloc", e);
+    int rc = slam_reserve(ctx, ctx->flags, 16 * sizeof(int32_t));
+    if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->record, 64 * sizeof(double));
+    if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->small, 1024 * sizeof(double));
+    if (rc != SLAM_OK) {
+        snprintf(g_create_err, sizeof g_create_err, "%s", ctx->err);
+        delete ctx;
+        return rc;
+    }
+    if ((e = hipMemsetAsync(ctx->flags.p, 0, 16 * sizeof(int32_t), ctx->stream)) != hipSuccess)
+        return fail("hipMemsetAsync", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    *out = ctx;
+    return SLAM_OK;
+}
+
+extern "C" void slam_destroy(slam_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    slam_buf* bufs[] = {&ctx->pts, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
+                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags};
+    for (slam_buf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->prof.created)
+        for (int i = 0; i < slam_prof::kMax; ++i) {
+            (void)hipEventDestroy(ctx->prof.start[i]);
+            (void)hipEventDestroy(ctx->prof.stop[i]);
+        }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char* slam_last_error(const slam_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+extern "C" int slam_set_stream(slam_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SLAM_OK;
+}
+
+extern "C" int slam_synchronize(slam_ctx* ctx) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// kernel timing
+// ================================================================================================
+static int prof_flush(slam_ctx* ctx) {
+    slam_prof& p = ctx->prof;
+    if (p.used == 0) return SLAM_OK;
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < p.used; ++i) {
+        float ms = 0.f;
+        SLAM_HIP(ctx, hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+        p.total_ms[p.kernel[i]] += ms;
+        p.launches[p.kernel[i]] += 1;
+    }
+    p.used = 0;
+    return SLAM_OK;
+}
+
+int slam_prof_slot(slam_ctx* ctx, int kernel) {
+    slam_prof& p = ctx->prof;
+    if (p.used == slam_prof::kMax && prof_flush(ctx) != SLAM_OK) return -1;
+    p.kernel[p.used] = kernel;
+    return p.used++;
+}
+
+extern "C" int slam_profile_enable(slam_ctx* ctx, int on) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->prof.created) {
+        for (int i = 0; i < slam_prof::kMax; ++i) {
+            SLAM_HIP(ctx, hipEventCreate(&ctx->prof.start[i]));
+            SLAM_HIP(ctx, hipEventCreate(&ctx->prof.stop[i]));
+        }
+        ctx->prof.created = true;
+    }
+    if (!on) SLAM_TRY(prof_flush(ctx));
+    ctx->profiling = on != 0;
+    return SLAM_OK;
+}
+
+extern "C" int slam_profile_read(slam_ctx* ctx, int kernel, double* total_ms, int64_t* launches) {
+    if (!ctx || kernel < 0 || kernel >= SLAM_K_COUNT) return SLAM_EINVAL;
+    SLAM_TRY(prof_flush(ctx));
+    if (total_ms) *total_ms = ctx->prof.total_ms[kernel];
+    if (launches) *launches = ctx->prof.launches[kernel];
+    return SLAM_OK;
+}
+
+extern "C" int slam_profile_reset(slam_ctx* ctx) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_TRY(prof_flush(ctx));
+    for (int k = 0; k < SLAM_K_COUNT; ++k) { ctx->prof.total_ms[k] = 0; ctx->prof.launches[k] = 0; }
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// sampler support: MT19937 output words after CPython's random.seed(int)
+//   (CPython Modules/_randommodule.c: init_genrand(19650218) then init_by_array(key), key = 32-bit words of the
+//    seed, least significant first; outputs are the tempered words of the first state regeneration)
+// ================================================================================================
+namespace {
+
+struct Mt19937 {
+    static const int N = 624, M = 397;
+    uint32_t mt[N];
+    void seed_by_array(const uint32_t* key, int klen) {
+        mt[0] = 19650218u;
+        for (int i = 1; i < N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        int i = 1, j = 0;
+        for (int k = std::max(N, klen); k > 0; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= N) { mt[0] = mt[N - 1]; i = 1; }
+            if (++j >= klen) j = 0;
+        }
+        for (int k = N - 1; k > 0; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= N) { mt[0] = mt[N - 1]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    // first `count` (<= N - M) outputs: word k of the regenerated state depends on old words k, k+1, k+M only
+    void first_outputs(uint32_t* out, int count) const {
+        for (int k = 0; k < count; ++k) {
+            uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+            y = mt[k + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[k] = y;
+        }
+    }
+};
+static_assert(SLAM_RAW_WORDS <= 624 - 397, "table row must come from the first regeneration block");
+
+}  // namespace
+
+// make ctx->raw cover iterations [it0, it0+n) of `seed`
+int slam_fill_raw_table(slam_ctx* ctx, uint64_t seed, int64_t it0, int64_t n) {
+    if (ctx->raw_n > 0 && ctx->raw_seed == seed && it0 >= ctx->raw_it0 && it0 + n <= ctx->raw_it0 + ctx->raw_n)
+        return SLAM_OK;
+    // regenerate, keeping the start when the request extends an existing table and rounding the size up
+    int64_t new_it0 = it0, new_n = n;
+    if (ctx->raw_n > 0 && ctx->raw_seed == seed && it0 >= ctx->raw_it0 && it0 <= ctx->raw_it0 + ctx->raw_n) {
+        new_it0 = ctx->raw_it0;
+        new_n = it0 + n - new_it0;
+    }
+    new_n = std::max<int64_t>(new_n + new_n / 2, 1024);
+    std::vector<uint32_t> host((size_t)new_n * SLAM_RAW_WORDS);
+    unsigned nthreads = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (new_n < 4096) nthreads = 1;
+    auto work = [&](int64_t lo, int64_t hi) {
+        Mt19937 g;
+        for (int64_t r = lo; r < hi; ++r) {
+            const uint64_t s = seed + (uint64_t)(new_it0 + r);
+            const uint32_t key[2] = {(uint32_t)s, (uint32_t)(s >> 32)};
+            g.seed_by_array(key, key[1] ? 2 : 1);
+            g.first_outputs(host.data() + (size_t)r * SLAM_RAW_WORDS, SLAM_RAW_WORDS);
+        }
+    };
+    if (nthreads == 1) {
+        work(0, new_n);
+    } else {
+        std::vector<std::thread> pool;
+        const int64_t per = (new_n + nthreads - 1) / nthreads;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            const int64_t lo = t * per, hi = std::min<int64_t>(new_n, lo + per);
+            if (lo < hi) pool.emplace_back(work, lo, hi);
+        }
+        for (auto& th : pool) th.join();
+    }
+    ctx->raw_n = 0;
+    SLAM_TRY(slam_reserve(ctx, ctx->raw, host.size() * sizeof(uint32_t)));
+    SLAM_HIP(ctx, hipMemcpyAsync(ctx->raw.p, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->raw_seed = seed;
+    ctx->raw_it0 = new_it0;
+    ctx->raw_n = new_n;
+    return SLAM_OK;
+}
+
+extern "C" int64_t slam_num_hypotheses(int64_t n_points, int64_t iterations) {
+    if (n_points < 8 || iterations < 0) return 0;
+    // C(n, 8), saturating: stop as soon as it exceeds `iterations`
+    unsigned __int128 c = 1;
+    for (int i = 1; i <= 8; ++i) {
+        c = c * (unsigned __int128)(n_points - 8 + i) / (unsigned)i;  // exact: c is C(n-8+i, i) after each step
+        if (c > (unsigned __int128)iterations) return iterations;     // C(n-8+i, i) only grows with i
+    }
+    return (int64_t)c;
+}
+
+static int check_flags(slam_ctx* ctx) {
+    SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->flags.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_flags[0] & 1) {
+        SLAM_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4 * sizeof(int32_t), ctx->stream));
+        snprintf(ctx->err, sizeof ctx->err, "sampler ran out of random words for at least one iteration");
+        return SLAM_ESAMPLER;
+    }
+    return SLAM_OK;
+}
+
+extern "C" int slam_sample_indices(slam_ctx* ctx, int kind, uint64_t seed, int64_t it0, int H, int N, int k,
+                                   int32_t* idx) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, idx != nullptr, "idx is NULL");
+    SLAM_REQUIRE(ctx, H >= 1 && it0 >= 0, "H < 1 or it0 < 0");
+    SLAM_REQUIRE(ctx, k >= 1 && k <= SLAM_MAX_K && N >= k, "need 1 <= k <= 16 and N >= k");
+    SLAM_REQUIRE(ctx, kind == SLAM_SAMPLER_CPYTHON || kind == SLAM_SAMPLER_COUNTER, "unknown sampler");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    if (kind == SLAM_SAMPLER_CPYTHON) SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));
+    SLAM_TRY(slam_reserve(ctx, ctx->idx, (size_t)H * k * sizeof(int32_t)));
+    SLAM_TRY(slam_launch(ctx, -1, k_sample, dim3((H + 63) / 64), dim3(64), 0, kind, seed, it0, H, N, k,
+                         (const uint32_t*)ctx->raw.p, ctx->raw_it0, (int32_t*)ctx->idx.p, (int32_t*)ctx->flags.p));
+    SLAM_HIP(ctx, hipMemcpyAsync(idx, ctx->idx.p, (size_t)H * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return check_flags(ctx);
+}
+
+// ================================================================================================
+// RANSAC
+// ================================================================================================
+template <int HB>
+static int launch_score_hb(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const double* F, int H,
+                           double thr, int32_t* counts, double* errsums) {
+    const dim3 grid((H + HB - 1) / HB), block(256);
+    // matches per lane and chunk: a function of N only, so that a hypothesis' errsum never depends on H or on
+    // how the hypotheses are spread over workgroups and GPUs
+    if (N <= 256) return slam_launch(ctx, SLAM_K_SCORE, k_score<HB, 1>, grid, block, 0, p0, p1, N, F, H, thr, counts, errsums);
+    if (N <= 1024) return slam_launch(ctx, SLAM_K_SCORE, k_score<HB, 4>, grid, block, 0, p0, p1, N, F, H, thr, counts, errsums);
+    return slam_launch(ctx, SLAM_K_SCORE, k_score<HB, 16>, grid, block, 0, p0, p1, N, F, H, thr, counts, errsums);
+}
+
+static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
+                          int sampler, uint64_t seed, int64_t it0, int H, double thr, double* d_record,
+                          uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all) {
+    SLAM_REQUIRE(ctx, d_p0 && d_p1 && d_record, "points or record pointer is NULL");
+    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");          // reference: src/epipolar.py:60
+    SLAM_REQUIRE(ctx, H >= 1 && it0 >= 0, "H < 1 or it0 < 0");
+    SLAM_REQUIRE(ctx, d_idx || sampler == SLAM_SAMPLER_CPYTHON || sampler == SLAM_SAMPLER_COUNTER, "unknown sampler");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    if (!d_F_all) { SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)H * 9 * sizeof(double))); d_F_all = (double*)ctx->F.p; }
+    if (!d_counts) { SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t))); d_counts = (int32_t*)ctx->counts.p; }
+    if (!d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double))); d_errsums = (double*)ctx->errsums.p; }
+    const double2* p0 = (const double2*)d_p0;
+    const double2* p1 = (const double2*)d_p1;
+    int32_t* flags = (int32_t*)ctx->flags.p;
+    const dim3 sgrid((H + 63) / 64), sblock(64);
+    if (d_idx) {
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<-1>, sgrid, sblock, 0, p0, p1, N, d_idx, (int32_t*)nullptr, seed,
+                             it0, H, (const uint32_t*)nullptr, (int64_t)0, d_F_all, flags));
+    } else if (sampler == SLAM_SAMPLER_CPYTHON) {
+        SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SLAM_SAMPLER_CPYTHON>, sgrid, sblock, 0, p0, p1, N,
+                             (const int32_t*)nullptr, (int32_t*)nullptr, seed, it0, H, (const uint32_t*)ctx->raw.p,
+                             ctx->raw_it0, d_F_all, flags));
+    } else {
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SLAM_SAMPLER_COUNTER>, sgrid, sblock, 0, p0, p1, N,
+                             (const int32_t*)nullptr, (int32_t*)nullptr, seed, it0, H, (const uint32_t*)nullptr,
+                             (int64_t)0, d_F_all, flags));
+    }
+    if (H >= 8192)
+        SLAM_TRY(launch_score_hb<8>(ctx, p0, p1, N, d_F_all, H, thr, d_counts, d_errsums));
+    else
+        SLAM_TRY(launch_score_hb<4>(ctx, p0, p1, N, d_F_all, H, thr, d_counts, d_errsums));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select, dim3(1), dim3(1024), 0, (const int32_t*)d_counts,
+                         (const double*)d_errsums, (const double*)d_F_all, H, it0, p0, p1, N, thr, d_record, d_mask));
+    return SLAM_OK;
+}
+
+extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
+                                 int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
+                                 uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all) {
+    if (!ctx) return SLAM_EINVAL;
+    return ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
+                          d_errsums, d_F_all);
+}
+
+// stage two (N,2) point arrays contiguously in ctx->pts; returns device pointers
+static int stage_points(slam_ctx* ctx, const double* p0, const double* p1, int64_t N, double** d0, double** d1) {
+    const size_t bytes = (size_t)N * 2 * sizeof(double);
+    SLAM_TRY(slam_reserve(ctx, ctx->pts, 2 * bytes + 64));
+    *d0 = (double*)ctx->pts.p;
+    *d1 = (double*)((char*)ctx->pts.p + ((bytes + 63) & ~(size_t)63));
+    SLAM_HIP(ctx, hipMemcpyAsync(*d0, p0, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(*d1, p1, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, int N, const int32_t* idx, int sampler,
+                             uint64_t seed, int64_t it0, int H, double threshold, double* record, uint8_t* mask,
+                             int32_t* counts, double* errsums, double* F_all) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, p0 && p1 && record, "points or record pointer is NULL");
+    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
+    SLAM_REQUIRE(ctx, H >= 1, "H < 1");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    double *d0, *d1;
+    SLAM_TRY(stage_points(ctx, p0, p1, N, &d0, &d1));
+    const int32_t* d_idx = nullptr;
+    if (idx) {
+        SLAM_TRY(slam_reserve(ctx, ctx->idx, (size_t)H * 8 * sizeof(int32_t)));
+        SLAM_HIP(ctx, hipMemcpyAsync(ctx->idx.p, idx, (size_t)H * 8 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        d_idx = (const int32_t*)ctx->idx.p;
+    }
+    uint8_t* d_mask = nullptr;
+    if (mask) { SLAM_TRY(slam_reserve(ctx, ctx->mask, (size_t)N)); d_mask = (uint8_t*)ctx->mask.p; }
+    SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)H * 9 * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t)));
+    SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
+    SLAM_TRY(ransac_enqueue(ctx, d0, d1, N, d_idx, sampler, seed, it0, H, threshold, (double*)ctx->record.p, d_mask,
+                            (int32_t*)ctx->counts.p, (double*)ctx->errsums.p, (double*)ctx->F.p));
+    SLAM_HIP(ctx, hipMemcpyAsync(record, ctx->record.p, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) SLAM_HIP(ctx, hipMemcpyAsync(mask, d_mask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts) SLAM_HIP(ctx, hipMemcpyAsync(counts, ctx->counts.p, (size_t)H * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (errsums) SLAM_HIP(ctx, hipMemcpyAsync(errsums, ctx->errsums.p, (size_t)H * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (F_all) SLAM_HIP(ctx, hipMemcpyAsync(F_all, ctx->F.p, (size_t)H * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return check_flags(ctx);
+}
+
+extern "C" int slam_merge_records(const double* records, int n_records, double* out) {
+    if (!records || !out || n_records < 1) return SLAM_EINVAL;
+    int best = 0;
+    for (int r = 1; r < n_records; ++r) {
+        const double* x = records + (size_t)r * SLAM_REC_LEN;
+        const double* y = records + (size_t)best * SLAM_REC_LEN;
+        bool wins;
+        if (x[SLAM_REC_COUNT] != y[SLAM_REC_COUNT]) wins = x[SLAM_REC_COUNT] > y[SLAM_REC_COUNT];
+        else if (x[SLAM_REC_ERRSUM] != y[SLAM_REC_ERRSUM]) wins = x[SLAM_REC_ERRSUM] < y[SLAM_REC_ERRSUM];
+        else wins = x[SLAM_REC_INDEX] < y[SLAM_REC_INDEX];
+        if (wins) best = r;
+    }
+    memcpy(out, records + (size_t)best * SLAM_REC_LEN, SLAM_REC_LEN * sizeof(double));
+    return best;
+}
+
+// ================================================================================================
+// eight-point solve
+// ================================================================================================
+extern "C" int slam_eightpoint(slam_ctx* ctx, const double* p0, const double* p1, int M, double* F) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, p0 && p1 && F, "NULL pointer");
+    SLAM_REQUIRE(ctx, M >= 8, "fewer than 8 matches");  // reference: src/epipolar.py:23
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    double *d0, *d1;
+    SLAM_TRY(stage_points(ctx, p0, p1, M, &d0, &d1));
+    double* dF = (double*)ctx->small.p + 512;
+    if (M == 8) {
+        static const int32_t iota[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+        SLAM_TRY(slam_reserve(ctx, ctx->idx, sizeof iota));
+        SLAM_HIP(ctx, hipMemcpyAsync(ctx->idx.p, iota, sizeof iota, hipMemcpyHostToDevice, ctx->stream));
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<-1>, dim3(1), dim3(64), 0, (const double2*)d0, (const double2*)d1, 8,
+                             (const int32_t*)ctx->idx.p, (int32_t*)nullptr, (uint64_t)0, (int64_t)0, 1,
+                             (const uint32_t*)nullptr, (int64_t)0, dF, (int32_t*)ctx->flags.p));
+    } else {
+        SLAM_TRY(slam_launch(ctx, -1, k_eightpoint_general, dim3(1), dim3(64), 0, (const double2*)d0, (const double2*)d1,
+                             M, dF));
+    }
+    SLAM_HIP(ctx, hipMemcpyAsync(F, dF, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// normalisation, F -> E
+// ================================================================================================
+extern "C" int slam_normalize_points(slam_ctx* ctx, const double* p, int N, double* out, double* T) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, p && out && T, "NULL pointer");
+    SLAM_REQUIRE(ctx, N >= 1, "no points");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)N * 2 * sizeof(double);
+    SLAM_TRY(slam_reserve(ctx, ctx->pts, 2 * bytes + 64));
+    double* din = (double*)ctx->pts.p;
+    double* dout = (double*)((char*)ctx->pts.p + ((bytes + 63) & ~(size_t)63));
+    double* dT = (double*)ctx->small.p + 512;
+    SLAM_HIP(ctx, hipMemcpyAsync(din, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, (const double2*)din, N, (double2*)dout, dT));
+    SLAM_HIP(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(T, dT, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_fundamental_to_essential(slam_ctx* ctx, const double* F, const double* K, double* E) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, F && K && E, "NULL pointer");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    double* dE = (double*)ctx->small.p + 512;
+    Mat3x2 fk;
+    memcpy(fk.A, F, sizeof fk.A);
+    memcpy(fk.B, K, sizeof fk.B);
+    SLAM_TRY(slam_launch(ctx, -1, k_f_to_e, dim3(1), dim3(64), 0, fk, dE));
+    SLAM_HIP(ctx, hipMemcpyAsync(E, dE, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// triangulation
+// ================================================================================================
+extern "C" int slam_triangulate_dev(slam_ctx* ctx, const double* P0_host, const double* P1_host, const double* d_p0,
+                                    const double* d_p1, int64_t N, double* d_X) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, P0_host && P1_host, "camera matrix pointer is NULL");
+    SLAM_REQUIRE(ctx, N >= 0 && N < ((int64_t)1 << 31) * 256, "N out of range");
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(ctx, d_p0 && d_p1 && d_X, "NULL pointer");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    Cams cams;  // the two 3x4 matrices travel as kernel arguments: nothing to stage, the call stays asynchronous
+    memcpy(cams.P0, P0_host, sizeof cams.P0);
+    memcpy(cams.P1, P1_host, sizeof cams.P1);
+    SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, cams,
+                         (const double2*)d_p0, (const double2*)d_p1, N, d_X));
+    return SLAM_OK;
+}
+
+extern "C" int slam_triangulate(slam_ctx* ctx, const double* P0, const double* P1, const double* p0, const double* p1,
+                                int64_t N, double* X) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, P0 && P1, "camera matrix pointer is NULL");
+    SLAM_REQUIRE(ctx, N >= 0, "N < 0");
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(ctx, p0 && p1 && X, "NULL pointer");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    double *d0, *d1;
+    SLAM_TRY(stage_points(ctx, p0, p1, N, &d0, &d1));
+    SLAM_TRY(slam_reserve(ctx, ctx->X, (size_t)N * 3 * sizeof(double)));
+    SLAM_TRY(slam_triangulate_dev(ctx, P0, P1, d0, d1, N, (double*)ctx->X.p));
+    SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// pose recovery
+// ================================================================================================
+static int tri4_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int64_t N, unsigned long long* d_counts4) {
+    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
+    return slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                       (const double*)ctx->small.p, (const double2*)d_p0, (const double2*)d_p1, N, (double*)ctx->X4.p,
+                       d_counts4);
+}
+
+extern "C" int slam_pose_candidates_dev(slam_ctx* ctx, const double* E_host, const double* K_host, const double* d_p0,
+                                        const double* d_p1, int64_t N, int64_t* d_counts4) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, E_host && K_host && d_p0 && d_p1 && d_counts4, "NULL pointer");
+    SLAM_REQUIRE(ctx, N >= 1 && N < ((int64_t)1 << 31) * 256, "N out of range");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    double* pw = (double*)ctx->small.p;
+    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
+    Mat3x2 ek;
+    memcpy(ek.A, E_host, sizeof ek.A);
+    memcpy(ek.B, K_host, sizeof ek.B);
+    SLAM_TRY(slam_launch(ctx, -1, k_pose_prepare, dim3(1), dim3(64), 0, ek, pw, (unsigned long long*)d_counts4));
+    return tri4_enqueue(ctx, d_p0, d_p1, N, (unsigned long long*)d_counts4);
+}
+
+extern "C" int slam_pose_select_dev(slam_ctx* ctx, const int64_t* d_counts4, int64_t N, double* d_pose, double* d_X,
+                                    int32_t* d_winner) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, d_counts4 && d_pose && d_winner, "NULL pointer");
+    SLAM_REQUIRE(ctx, N >= 1 && ctx->X4.cap >= (size_t)4 * (size_t)N * 3 * sizeof(double),
+                 "slam_pose_candidates_dev must run first with the same N");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    SLAM_TRY(slam_launch(ctx, -1, k_pose_select, dim3(1), dim3(64), 0, (const double*)ctx->small.p,
+                         (const unsigned long long*)d_counts4, d_pose, d_winner));
+    if (d_X) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((N * 3 + 255) / 256, 4096);
+        SLAM_TRY(slam_launch(ctx, -1, k_emit_points, dim3(blocks), dim3(256), 0, (const double*)ctx->X4.p,
+                             (const int32_t*)d_winner, N, d_X, (uint8_t*)nullptr));
+    }
+    return SLAM_OK;
+}
+
+extern "C" int slam_pose_from_E(slam_ctx* ctx, const double* E, const double* K, const double* p0, const double* p1,
+                                int64_t N, double* pose, double* X, int32_t* counts4, int32_t* winner) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, E && K && p0 && p1 && pose && X, "NULL pointer");
+    SLAM_REQUIRE(ctx, N >= 1, "no points");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    double *d0, *d1;
+    SLAM_TRY(stage_points(ctx, p0, p1, N, &d0, &d1));
+    SLAM_TRY(slam_reserve(ctx, ctx->X, (size_t)N * 3 * sizeof(double)));
+    double* small = (double*)ctx->small.p;
+    int64_t* d_counts4 = (int64_t*)(small + 700);
+    double* d_pose = small + 710;
+    int32_t* d_winner = (int32_t*)(small + 730);
+    SLAM_TRY(slam_pose_candidates_dev(ctx, E, K, d0, d1, N, d_counts4));
+    SLAM_TRY(slam_pose_select_dev(ctx, d_counts4, N, d_pose, (double*)ctx->X.p, d_winner));
+    SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_small + 32, d_counts4, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_small + 40, d_pose, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_small + 60, d_winner, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(pose, ctx->h_small + 40, 16 * sizeof(double));
+    const int64_t* c = (const int64_t*)(ctx->h_small + 32);
+    if (counts4) for (int i = 0; i < 4; ++i) counts4[i] = (int32_t)c[i];
+    if (winner) *winner = *(const int32_t*)(ctx->h_small + 60);
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// whole pair
+// ================================================================================================
+extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* pts1, int N, const double* K,
+                              int iterations, double* F, double* E, double* pose, double* X, uint8_t* good,
+                              double* record, int32_t* counts4, int32_t* winner) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, pts0 && pts1 && K, "NULL pointer");
+    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
+    SLAM_REQUIRE(ctx, iterations >= 1, "iterations < 1");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int H = (int)slam_num_hypotheses(N, iterations);
+    const size_t bytes = (size_t)N * 2 * sizeof(double), stride = (bytes + 63) & ~(size_t)63;
+    // pts: raw0 | raw1 | norm0 | norm1
+    SLAM_TRY(slam_reserve(ctx, ctx->pts, 4 * stride + 64));
+    char* base = (char*)ctx->pts.p;
+    double *r0 = (double*)base, *r1 = (double*)(base + stride), *n0 = (double*)(base + 2 * stride),
+           *n1 = (double*)(base + 3 * stride);
+    SLAM_TRY(slam_reserve(ctx, ctx->X, (size_t)N * 3 * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->mask, (size_t)N));
+    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)H * 9 * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t)));
+    SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
+    SLAM_TRY(slam_fill_raw_table(ctx, SLAM_SEED_BASE, 0, H));
+    double* small = (double*)ctx->small.p;
+    double* pw = small;
+    unsigned long long* d_counts4 = (unsigned long long*)(small + 700);
+    double* d_pose = small + 710;
+    int32_t* d_winner = (int32_t*)(small + 730);
+    double* d_record = (double*)ctx->record.p;
+    SLAM_HIP(ctx, hipMemcpyAsync(r0, pts0, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(r1, pts1, bytes, hipMemcpyHostToDevice, ctx->stream));
+    Mat3x2 kk;
+    memcpy(kk.A, K, sizeof kk.A);
+    memset(kk.B, 0, sizeof kk.B);
+    SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, (const double2*)r0, N, (double2*)n0, pw + PW_T0));
+    SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, (const double2*)r1, N, (double2*)n1, pw + PW_T1));
+    SLAM_TRY(ransac_enqueue(ctx, n0, n1, N, nullptr, SLAM_SAMPLER_CPYTHON, SLAM_SEED_BASE, 0, H, SLAM_DEFAULT_THRESHOLD,
+                            d_record, nullptr, nullptr, nullptr, nullptr));
+    SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1), dim3(64), 0, kk, (const double*)d_record, pw, d_counts4));
+    SLAM_TRY(tri4_enqueue(ctx, r0, r1, N, d_counts4));
+    SLAM_TRY(slam_launch(ctx, -1, k_pose_select, dim3(1), dim3(64), 0, (const double*)pw,
+                         (const unsigned long long*)d_counts4, d_pose, d_winner));
+    const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)N * 3 + 255) / 256, 4096);
+    SLAM_TRY(slam_launch(ctx, -1, k_emit_points, dim3(blocks), dim3(256), 0, (const double*)ctx->X4.p,
+                         (const int32_t*)d_winner, (int64_t)N, (double*)ctx->X.p, (uint8_t*)ctx->mask.p));
+    if (X) SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (good) SLAM_HIP(ctx, hipMemcpyAsync(good, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    double* hs = ctx->h_small;
+    SLAM_HIP(ctx, hipMemcpyAsync(hs, pw + PW_E, 18 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));  // E, F
+    SLAM_HIP(ctx, hipMemcpyAsync(hs + 32, d_counts4, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(hs + 40, d_pose, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(hs + 60, d_winner, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(hs + 64, d_record, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_TRY(check_flags(ctx));
+    if (E) memcpy(E, hs, 9 * sizeof(double));
+    if (F) memcpy(F, hs + 9, 9 * sizeof(double));
+    if (pose) memcpy(pose, hs + 40, 16 * sizeof(double));
+    if (record) memcpy(record, hs + 64, SLAM_REC_LEN * sizeof(double));
+    const int64_t* c = (const int64_t*)(hs + 32);
+    if (counts4) for (int i = 0; i < 4; ++i) counts4[i] = (int32_t)c[i];
+    if (winner) *winner = *(const int32_t*)(hs + 60);
+    return SLAM_OK;
+}

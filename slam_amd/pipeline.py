@@ -1,0 +1,97 @@
+"""Caller-side glue of the reference driver (custom_slam.py:85-115) on the GPU, plus the multi-GPU exchange."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._lib import REC_LEN, f64, ptr
+
+
+def normalize_points(points, ctx=None):
+    """(points - mean) / s and the matrix T the reference pairs with it, s = mean distance / sqrt(2)
+    (reference: custom_slam.py:85-93; T carries s where a similarity would carry 1/s, as there)."""
+    p = f64(np.asarray(points))
+    assert p.ndim == 2 and p.shape[1] == 2 and len(p) >= 1
+    ctx = ctx or _lib.default_context()
+    out = np.empty_like(p)
+    T = np.empty((3, 3))
+    ctx.check(ctx.lib.slam_normalize_points(ctx.handle, ptr(p), len(p), ptr(out), ptr(T)))
+    return out, T
+
+
+def normalize_points_and_find_fundamental_matrix(img0_points, img1_points, iterations=1000):
+    """reference: custom_slam.py:96-102"""
+    from . import epipolar
+    n0, T0 = normalize_points(img0_points)
+    n1, T1 = normalize_points(img1_points)
+    F = epipolar.calculate_fundamental_matrix_with_ransac(n0, n1, iterations)
+    return T1.T @ F @ T0
+
+
+def initialise_pair(img0_points, img1_points, intrinsic_camera_matrix, iterations=1000, ctx=None):
+    """Whole two-view initialisation of one pair with one upload and one download
+    (normalise, RANSAC, denormalise, F->E, pose, z>0 flags: custom_slam.py:96-115 after the matching step)."""
+    p0 = f64(np.asarray(img0_points))
+    p1 = f64(np.asarray(img1_points))
+    K = f64(intrinsic_camera_matrix)
+    assert p0.shape == p1.shape and p0.ndim == 2 and p0.shape[1] == 2
+    assert len(p0) >= 8
+    ctx = ctx or _lib.default_context()
+    N = len(p0)
+    F, E, pose = np.empty((3, 3)), np.empty((3, 3)), np.empty((4, 4))
+    X = np.empty((N, 3))
+    good = np.empty(N, dtype=np.uint8)
+    record = np.empty(REC_LEN)
+    counts4 = np.empty(4, dtype=np.int32)
+    winner = np.empty(1, dtype=np.int32)
+    ctx.check(ctx.lib.slam_init_pair(ctx.handle, ptr(p0), ptr(p1), N, ptr(K), int(iterations), ptr(F), ptr(E), ptr(pose),
+                                     ptr(X), ptr(good), ptr(record), ptr(counts4), ptr(winner)))
+    return dict(F=F, E=E, pose=pose, X=X, mask=good.astype(bool), record=record, counts=counts4, winner=int(winner[0]))
+
+
+def find_pose_and_triangulated_points(img0_points, img1_points, intrinsic_camera_matrix, iterations=1000):
+    """The reference's return tuple (custom_slam.py:105-115), starting from matches instead of images."""
+    r = initialise_pair(img0_points, img1_points, intrinsic_camera_matrix, iterations)
+    return r["pose"], [np.asarray(img0_points), np.asarray(img1_points)], r["X"], r["mask"]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU: hypothesis ranges per rank, one all-gather of the 96-byte winner records, same rule on every rank
+# ------------------------------------------------------------------------------------------------------------------
+def better_record(x, y):
+    """True if record x beats record y under the reference's rule (src/epipolar.py:78-81) extended across ranks:
+    more inliers, else smaller inlier-error sum, else earlier iteration."""
+    if x[_lib.REC_COUNT] != y[_lib.REC_COUNT]:
+        return x[_lib.REC_COUNT] > y[_lib.REC_COUNT]
+    if x[_lib.REC_ERRSUM] != y[_lib.REC_ERRSUM]:
+        return x[_lib.REC_ERRSUM] < y[_lib.REC_ERRSUM]
+    return x[_lib.REC_INDEX] < y[_lib.REC_INDEX]
+
+
+def merge_records(records):
+    """Winner among per-rank records ((R, 12) array-like); pure host logic, usable without a GPU."""
+    records = np.asarray(records, dtype=np.float64).reshape(-1, REC_LEN)
+    best = 0
+    for r in range(1, len(records)):
+        if better_record(records[r], records[best]):
+            best = r
+    return best, records[best].copy()
+
+
+def shard_range(total, rank, world):
+    """Contiguous hypothesis range [lo, hi) of `rank`; ranges differ in size by at most one."""
+    base, extra = divmod(int(total), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allgather_winner(local_record, group=None):
+    """All-gather the local winner record over torch.distributed (RCCL for CUDA tensors, gloo for CPU tensors)
+    and apply the selection rule; every rank returns the same (rank_of_winner, record)."""
+    import torch
+    import torch.distributed as dist
+    t = local_record if isinstance(local_record, torch.Tensor) else torch.from_numpy(np.asarray(local_record, dtype=np.float64))
+    world = dist.get_world_size(group)
+    out = torch.empty((world, REC_LEN), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t.reshape(1, REC_LEN).contiguous(), group=group)
+    return merge_records(out.cpu().numpy())

@@ -9,8 +9,9 @@ With N>1 GPUs every rank runs its own frame pair (pairs are independent: no data
 GPU is fixed ("weak" scaling) and value = hypotheses scored by all ranks / wall time of the slowest rank.
 
 One JSON line is printed by rank 0.  Besides the contract fields it carries
-  roofline      the scoring kernel against the FP64 vector-ALU peak (its bound: see DESIGN.md), durations from HIP
-                events attached to each launch on the library's stream during a second timed pass of K steps
+  roofline      the dominant kernel (k_ransac: sample + solve + score fused) against the FP64 vector-ALU peak (its
+                bound: see DESIGN.md), counting the scoring flops only; durations from HIP events attached to each
+                launch on the library's stream during a second timed pass of K steps
   cpu_baseline  the C restatement in oracle/ timed on this host's cores (rank 0, N=1 only)
   aux           bulk triangulation + cheirality throughput (4 candidates per point) with its own roofline
 """
@@ -109,7 +110,7 @@ def main():
         step()
     barrier()
     kern = {}
-    for name, kid in (("solve", _lib.K_SOLVE), ("score", _lib.K_SCORE), ("select", _lib.K_SELECT)):
+    for name, kid in (("score", _lib.K_SCORE), ("select", _lib.K_SELECT)):
         ms, n = C.c_double(0), C.c_int64(0)
         ctx.check(lib.slam_profile_read(ctx.handle, kid, C.byref(ms), C.byref(n)))
         kern[name] = (ms.value / max(n.value, 1)) * 1e3      # us per launch
@@ -120,14 +121,14 @@ def main():
     tpath = os.path.join(REPO, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_score_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("k_ransac_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "k_score", "bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU,
+    roofline = {"kernel": "k_ransac (sample+solve+score)", "bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU, "traffic": traffic,
                 "avg_launch_us": score_us, "flop_per_launch": FLOP_PER_EVAL * N_HYP * N_MATCHES,
                 "algorithmic_bytes_per_launch": N_MATCHES * 32 + N_HYP * 72 + N_HYP * 12,
-                "other_kernels_us": {"k_solve": kern["solve"], "k_select": kern["select"]}}
+                "other_kernels_us": {"k_select": kern["select"]}}
 
     out = {"metric": "RANSAC 8-pt hypotheses scored/sec @N=4096 matches", "value": value, "unit": "hypotheses/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

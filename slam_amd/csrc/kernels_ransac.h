@@ -7,6 +7,20 @@
 
 namespace slamk {
 
+#ifdef SLAM_STAMPS
+// diagnostic build only: shader-clock stamps of workgroup phases, read back by slam_debug_stamps()
+__device__ long long g_stamps[4096 * 8];
+#define SLAM_STAMP(slot)                                                                        \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (slot)] = clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+#else
+#define SLAM_STAMP(slot) do { } while (0)
+#endif
+
+
 // ------------------------------------------------------------------------------------------------
 // Samplers.  Both produce k distinct indices in [0, N) per iteration, in draw order.
 // ------------------------------------------------------------------------------------------------
@@ -14,25 +28,30 @@ namespace slamk {
 // CPython's  random.seed(s); random.sample(range(N), k)  (reference: src/epipolar.py:70-71) replayed from the
 // first SLAM_RAW_WORDS tempered MT19937 words of that seed.  getrandbits(b) is word >> (32 - b); _randbelow
 // rejects values >= n; sample() swaps out of a pool when N <= setsize and rejects repeats otherwise.
+// The first SLAM_PREFETCH_WORDS words of a lane's row are staged in LDS with one round of wide loads, so the
+// data-dependent consumption loop does not pay a global-memory latency per word.
+#define SLAM_PREFETCH_WORDS 32
+#define SLAM_MAX_K 16
+#define SLAM_POOL_MAX 85  // setsize of sample() for 6 <= k <= 21: 21 + 4^ceil(log4(3k)) = 85
+
 struct RawStream {
-    const uint32_t* w;
+    const uint32_t* row;  // this lane's row in the global table
+    const uint32_t* lds;  // this lane's column in LDS: word j at lds[j * stride]
+    int stride;
     int pos;
-    int limit;
     bool overflow;
-    __device__ uint32_t below(uint32_t n) {
-        const int bits = 32 - __clz(n);
-        uint32_t r = n;  // invalid until a word is accepted
-        while (pos < limit) {
-            r = w[pos++] >> (32 - bits);
+    __device__ __forceinline__ uint32_t below(uint32_t n) {
+        const int shift = __clz(n);  // 32 - bit_length(n)
+        while (pos < SLAM_RAW_WORDS) {
+            const uint32_t w = pos < SLAM_PREFETCH_WORDS ? lds[pos * stride] : row[pos];
+            ++pos;
+            const uint32_t r = w >> shift;
             if (r < n) return r;
         }
         overflow = true;
         return 0;
     }
 };
-
-#define SLAM_MAX_K 16
-#define SLAM_POOL_MAX 85  // setsize of sample() for 6 <= k <= 21: 21 + 4^ceil(log4(3k)) = 85
 
 __device__ __forceinline__ int sample_setsize(int k) {
     int s = 21;
@@ -44,10 +63,27 @@ __device__ __forceinline__ int sample_setsize(int k) {
     return s;
 }
 
-// pool: LDS bytes [SLAM_POOL_MAX][blockDim.x] (lane-minor), only touched when N <= setsize
-__device__ __forceinline__ bool sample_cpython(const uint32_t* raw_row, int raw_words, int N, int k, int32_t* out,
+// stage the first SLAM_PREFETCH_WORDS words of `row` into this lane's LDS column (8 x 16-byte loads in flight)
+__device__ __forceinline__ void stage_words(const uint32_t* row, uint32_t* lds, int stride) {
+    const uint4* src = (const uint4*)row;  // rows are 384 B apart and the table is 256-B aligned
+    uint4 v[SLAM_PREFETCH_WORDS / 4];
+#pragma unroll
+    for (int q = 0; q < SLAM_PREFETCH_WORDS / 4; ++q) v[q] = src[q];
+#pragma unroll
+    for (int q = 0; q < SLAM_PREFETCH_WORDS / 4; ++q) {
+        lds[(4 * q + 0) * stride] = v[q].x;
+        lds[(4 * q + 1) * stride] = v[q].y;
+        lds[(4 * q + 2) * stride] = v[q].z;
+        lds[(4 * q + 3) * stride] = v[q].w;
+    }
+}
+
+// words: LDS [SLAM_PREFETCH_WORDS][lanes]; pool: LDS bytes [SLAM_POOL_MAX][lanes] (lane-minor), touched only
+// when N <= setsize.  `lane` is this lane's column, `lanes` the number of columns.
+__device__ __forceinline__ bool sample_cpython(const uint32_t* raw_row, int N, int k, int32_t* out, uint32_t* words,
                                                uint8_t* pool, int lane, int lanes) {
-    RawStream rs{raw_row, 0, raw_words, false};
+    stage_words(raw_row, words + lane, lanes);
+    RawStream rs{raw_row, words + lane, lanes, 0, false};
     if (N <= sample_setsize(k)) {
         for (int i = 0; i < N; ++i) pool[i * lanes + lane] = (uint8_t)i;
         for (int i = 0; i < k; ++i) {
@@ -75,13 +111,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0;
+        const uint32_t n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -89,22 +123,136 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // word stream of iteration `it`: block b = philox(counter = (b, 0, it_lo, it_hi), key = seed); index = word >>
-// (32 - bitlen(N)), rejected when >= N or already drawn.
-__device__ __forceinline__ bool sample_counter(uint64_t seed, uint64_t it, int N, int k, int32_t* out) {
-    const int bits = 32 - __clz((uint32_t)N);
-    uint32_t w[4];
-    int have = 0, i = 0;
+// (32 - bitlen(N)), rejected when >= N or already drawn.  k <= 8 indices go to out[0..7] (static indexing only).
+__device__ __forceinline__ bool sample_counter8(uint64_t seed, uint64_t it, int N, int k, int32_t (&out)[8]) {
+    const int shift = __clz((uint32_t)N);
+    int i = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[q] = -1;
     for (uint32_t blk = 0; blk < 4096u && i < k; ++blk) {
+        uint32_t w[4];
         philox4x32_10(blk, 0u, (uint32_t)it, (uint32_t)(it >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-        have = 4;
-        for (int u = 0; u < have && i < k; ++u) {
-            const uint32_t j = w[u] >> (32 - bits);
-            bool bad = j >= (uint32_t)N;
-            for (int q = 0; q < i; ++q) bad |= (out[q] == (int32_t)j);
-            if (!bad) out[i++] = (int32_t)j;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t j = (int32_t)(w[u] >> shift);
+            bool ok = (j < N) && (i < k);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ok &= (out[q] != j);  // unused slots hold -1
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] = (ok && q == i) ? j : out[q];
+            i += ok ? 1 : 0;
         }
     }
     return i == k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-parallel draw of ONE iteration's 8 indices: lane l looks at word l of the iteration's stream.
+// Sequential semantics being reproduced (set path of random.sample, and the counter sampler): walk the words in
+// order, drop a word whose value is >= N or equals an already accepted value, stop at 8 accepted values.
+// A word is dropped as a repeat exactly when an EARLIER in-range word has the same value, so acceptance can be
+// decided for all lanes at once.  Only the first 16 in-range words are considered; if they hold fewer than 8
+// distinct values (or the 64 words run out) the caller falls back to the sequential walk.
+// All 64 lanes must be active and pass the same arguments apart from `word`.  sel[] is wave-uniform.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool select8_from_words(uint32_t word, int N, int32_t (&sel)[8]) {
+    const int lane = threadIdx.x & 63;
+    const int32_t r = (int32_t)(word >> __clz((uint32_t)N));
+    const bool valid = r < N;
+    unsigned long long vmask = __ballot(valid);
+    const int my_rank = __popcll(vmask & ((1ull << lane) - 1ull));  // in-range words before this lane
+    bool repeat = false;
+    unsigned long long rest = vmask;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (rest) {  // wave-uniform
+            const int src = __ffsll((long long)rest) - 1;
+            rest &= rest - 1ull;
+            const int32_t rq = __builtin_amdgcn_readlane(r, src);
+            repeat |= valid && (q < my_rank) && (rq == r);
+        }
+    }
+    unsigned long long amask = __ballot(valid && !repeat && my_rank < 16);
+    if (__popcll(amask) < 8) return false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int src = __ffsll((long long)amask) - 1;
+        amask &= amask - 1ull;
+        sel[q] = __builtin_amdgcn_readlane(r, src);
+    }
+    return true;
+}
+
+// sequential walk over a lane-private copy of the stream (used when the wave-parallel draw does not apply)
+__device__ __forceinline__ bool sample_cpython_seq(const uint32_t* row, int N, int k, int32_t* out, uint8_t* pool,
+                                                   int lane, int lanes) {
+    int pos = 0;
+    bool overflow = false;
+    auto below = [&](uint32_t n) -> uint32_t {
+        const int shift = __clz(n);
+        while (pos < SLAM_RAW_WORDS) {
+            const uint32_t r = row[pos++] >> shift;
+            if (r < n) return r;
+        }
+        overflow = true;
+        return 0u;
+    };
+    if (N <= sample_setsize(k)) {
+        for (int i = 0; i < N; ++i) pool[i * lanes + lane] = (uint8_t)i;
+        for (int i = 0; i < k; ++i) {
+            const uint32_t j = below((uint32_t)(N - i));
+            out[i] = pool[j * lanes + lane];
+            pool[j * lanes + lane] = pool[(N - i - 1) * lanes + lane];
+        }
+    } else {
+        for (int i = 0; i < k; ++i) {
+            uint32_t j;
+            bool dup;
+            do {
+                j = below((uint32_t)N);
+                dup = false;
+                for (int q = 0; q < i; ++q) dup |= (out[q] == (int32_t)j);
+            } while (dup && !overflow);
+            out[i] = (int32_t)j;
+        }
+    }
+    return !overflow;
+}
+
+// One iteration's 8 indices for a whole wave (wave-uniform result).  SAMPLER: -1 = given, else SLAM_SAMPLER_*.
+// word0: this lane's word of the iteration's MT19937 row (CPython sampler only).
+// pool: LDS bytes [SLAM_POOL_MAX] private to this wave.
+template <int SAMPLER>
+__device__ __forceinline__ bool indices_for_wave(int h, int N, uint32_t word0, const int32_t* __restrict__ idx_in,
+                                                 uint64_t seed, int64_t it0, const uint32_t* __restrict__ raw,
+                                                 int64_t raw_it0, uint8_t* pool, int32_t (&sel)[8]) {
+    const int lane = threadIdx.x & 63;
+    if (SAMPLER < 0) {
+        const int32_t v = idx_in[(size_t)h * 8 + (lane & 7)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sel[q] = __builtin_amdgcn_readlane(v, q);
+        return true;
+    } else if (SAMPLER == SLAM_SAMPLER_CPYTHON) {
+        const uint32_t* row = raw + (size_t)(it0 + h - raw_it0) * SLAM_RAW_WORDS;
+        if (N > sample_setsize(8)) {  // set path of random.sample; word0 = row[lane], loaded by the caller
+            if (select8_from_words(word0, N, sel)) return true;
+        }
+        // pool path (N <= 85) or a draw that needs more than the first 16 in-range words: sequential, on lane 0
+        int32_t out[8];
+        bool ok = true;
+        if (lane == 0) ok = sample_cpython_seq(row, N, 8, out, pool, 0, 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sel[q] = __builtin_amdgcn_readlane(out[q], 0);
+        return __builtin_amdgcn_readlane((int)ok, 0) != 0;
+    } else {
+        uint32_t w[4];
+        philox4x32_10((uint32_t)(lane >> 2), 0u, (uint32_t)(it0 + h), (uint32_t)((uint64_t)(it0 + h) >> 32),
+                      (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        const int u = lane & 3;
+        const uint32_t word = u == 0 ? w[0] : (u == 1 ? w[1] : (u == 2 ? w[2] : w[3]));
+        if (select8_from_words(word, N, sel)) return true;
+        return sample_counter8(seed, (uint64_t)(it0 + h), N, 8, sel);  // every lane walks the same stream
+    }
 }
 
 // standalone sampling kernel (slam_sample_indices): one lane per iteration
@@ -112,52 +260,30 @@ __global__ __launch_bounds__(64) void k_sample(int kind, uint64_t seed, int64_t 
                                                const uint32_t* __restrict__ raw, int64_t raw_it0,
                                                int32_t* __restrict__ idx, int32_t* __restrict__ flags) {
     __shared__ uint8_t pool[SLAM_POOL_MAX * 64];
+    __shared__ uint32_t words[SLAM_PREFETCH_WORDS * 64];
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= H) return;
-    int32_t out[SLAM_MAX_K];
     bool ok;
-    if (kind == SLAM_SAMPLER_CPYTHON)
-        ok = sample_cpython(raw + (size_t)(it0 + h - raw_it0) * SLAM_RAW_WORDS, SLAM_RAW_WORDS, N, k, out, pool,
-                            threadIdx.x, 64);
-    else
-        ok = sample_counter(seed, (uint64_t)(it0 + h), N, k, out);
+    if (kind == SLAM_SAMPLER_CPYTHON) {
+        int32_t out[SLAM_MAX_K];
+        ok = sample_cpython(raw + (size_t)(it0 + h - raw_it0) * SLAM_RAW_WORDS, N, k, out, words, pool, threadIdx.x, 64);
+        for (int i = 0; i < k; ++i) idx[(size_t)h * k + i] = out[i];
+    } else {
+        int32_t out[8];
+        ok = sample_counter8(seed, (uint64_t)(it0 + h), N, k, out);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < k) idx[(size_t)h * k + i] = out[i];
+    }
     if (!ok) atomicOr(&flags[0], 1);
-    for (int i = 0; i < k; ++i) idx[(size_t)h * k + i] = out[i];
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: eight-point solve, one lane per hypothesis   (reference: src/epipolar.py:37-51)
+// Eight-point solve of one hypothesis on one lane   (reference: src/epipolar.py:37-51)
 //   rows c = [b0 a0, b0 a1, b0, b1 a0, b1 a1, b1, a0, a1, 1]; f = null vector; f/||f||; rank-2 projection.
-// SAMPLER: -1 = indices given, otherwise SLAM_SAMPLER_* drawn in-kernel (and stored to idx_out when non-null).
 // ------------------------------------------------------------------------------------------------
-template <int SAMPLER>
-__global__ __launch_bounds__(64) void k_solve(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
-                                              const int32_t* __restrict__ idx_in, int32_t* __restrict__ idx_out,
-                                              uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw,
-                                              int64_t raw_it0, double* __restrict__ Fout,
-                                              int32_t* __restrict__ flags) {
-    __shared__ uint8_t pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * 64 : 1];
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= H) return;
-
-    int32_t sel[8];
-    if (SAMPLER < 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sel[i] = idx_in[(size_t)h * 8 + i];
-    } else {
-        bool ok;
-        if (SAMPLER == SLAM_SAMPLER_CPYTHON)
-            ok = sample_cpython(raw + (size_t)(it0 + h - raw_it0) * SLAM_RAW_WORDS, SLAM_RAW_WORDS, N, 8, sel, pool,
-                                threadIdx.x, 64);
-        else
-            ok = sample_counter(seed, (uint64_t)(it0 + h), N, 8, sel);
-        if (!ok) atomicOr(&flags[0], 1);
-        if (idx_out) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) idx_out[(size_t)h * 8 + i] = sel[i];
-        }
-    }
-
+__device__ __forceinline__ void solve_from_indices(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
+                                                   const int32_t (&sel)[8], double (&F)[9]) {
     double A[9][8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -167,83 +293,218 @@ __global__ __launch_bounds__(64) void k_solve(const double2* __restrict__ p0, co
         A[3][c] = b.y * a.x; A[4][c] = b.y * a.y; A[5][c] = b.y;
         A[6][c] = a.x;       A[7][c] = a.y;       A[8][c] = 1.0;
     }
-    double f[9], F[9];
+    double f[9];
     null_vector_9x8(A, f);
     rank2_project(f, F);
+}
+
+// draw (or read) the 8 indices of iteration it0 + h.  SAMPLER: -1 = given in idx_in, else SLAM_SAMPLER_*.
+// words/pool: LDS with `lanes` columns, this lane using column `lane`.
+template <int SAMPLER>
+__device__ __forceinline__ bool indices_for(int h, int N, const int32_t* __restrict__ idx_in, uint64_t seed, int64_t it0,
+                                            const uint32_t* __restrict__ raw, int64_t raw_it0, uint32_t* words,
+                                            uint8_t* pool, int lane, int lanes, int32_t (&sel)[8]) {
+    if (SAMPLER < 0) {
+        const int4 lo = ((const int4*)idx_in)[2 * (size_t)h], hi = ((const int4*)idx_in)[2 * (size_t)h + 1];
+        sel[0] = lo.x; sel[1] = lo.y; sel[2] = lo.z; sel[3] = lo.w;
+        sel[4] = hi.x; sel[5] = hi.y; sel[6] = hi.z; sel[7] = hi.w;
+        return true;
+    } else if (SAMPLER == SLAM_SAMPLER_CPYTHON) {
+        return sample_cpython(raw + (size_t)(it0 + h - raw_it0) * SLAM_RAW_WORDS, N, 8, sel, words, pool, lane, lanes);
+    } else {
+        return sample_counter8(seed, (uint64_t)(it0 + h), N, 8, sel);
+    }
+}
+
+// K1 standalone: one lane per hypothesis.  Used for single solves and for large H, where 64 hypotheses per wave
+// keep the vector units busy during the (latency-bound) solve.
+template <int SAMPLER>
+__global__ __launch_bounds__(64) void k_solve(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
+                                              const int32_t* __restrict__ idx_in, uint64_t seed, int64_t it0, int H,
+                                              const uint32_t* __restrict__ raw, int64_t raw_it0,
+                                              double* __restrict__ Fout, int32_t* __restrict__ flags) {
+    __shared__ uint32_t s_words[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_PREFETCH_WORDS * 64 : 1];
+    __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * 64 : 1];
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    int32_t sel[8];
+    const bool ok = indices_for<SAMPLER>(h, N, idx_in, seed, it0, raw, raw_it0, s_words, s_pool, threadIdx.x, 64, sel);
+    if (!ok) atomicOr(&flags[0], 1);
+    double F[9];
+    solve_from_indices(p0, p1, N, sel, F);
 #pragma unroll
     for (int i = 0; i < 9; ++i) Fout[(size_t)h * 9 + i] = F[i];
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: scoring   (reference: src/epipolar.py:73-77)
+// Scoring   (reference: src/epipolar.py:73-77)
 //   r = (x1^T F) x0 with x = (u, v, 1); err = r^2; inlier iff err < thr (strict); count and sum of inlier err.
-// One workgroup scores HB hypotheses against ALL N matches: each lane keeps PPL matches of a chunk in registers
-// and loops over the hypotheses, whose F arrive through uniform (scalar) loads.  Per-hypothesis sums are combined
-// in a fixed order (lane partials over chunks, xor-butterfly over the 64 lanes, waves in order), so a hypothesis
-// gets the same errsum whichever workgroup, launch or GPU scores it.
+// The test fl(r*r) < thr is evaluated as |r| < rcut, which is the same predicate for every double r because the
+// rounded square is monotone in |r| (rcut is found on the host: square_cutoff()); the sum adds r*r by fma.
+// A workgroup of WAVES waves scores HB hypotheses (F in LDS) against ALL N matches: each lane keeps PPL matches of
+// a chunk of 64*WAVES*PPL in registers and loops over the hypotheses.  Per-hypothesis sums are combined in a
+// fixed order (lane partials over chunks, wave_sum_f64 over the 64 lanes, waves in order) that depends on N only,
+// so a hypothesis gets the same errsum whichever kernel, workgroup, launch or GPU scores it.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum_f64(double v) {
+template <int PPL, int WAVES>
+struct MatchChunk {  // PPL matches per lane of a chunk of 64*WAVES*PPL, plus which of them are real
+    double a0[PPL], a1[PPL], b0[PPL], b1[PPL];
+    bool live[PPL];
+    unsigned long long livemask[PPL];  // the same as wave-uniform lane masks
+    __device__ __forceinline__ void load(const double2* __restrict__ p0, const double2* __restrict__ p1, int N, int base) {
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+        for (int k = 0; k < PPL; ++k) {
+            const int i = base + k * 64 * WAVES + (int)threadIdx.x;
+            live[k] = i < N;
+            livemask[k] = __ballot(live[k]);
+            const int ii = live[k] ? i : N - 1;
+            const double2 a = p0[ii], b = p1[ii];
+            a0[k] = a.x; a1[k] = a.y; b0[k] = b.x; b1[k] = b.y;
+        }
+    }
+};
 
-template <int HB, int PPL>
-__global__ __launch_bounds__(256) void k_score(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
-                                               const double* __restrict__ Fall, int H, double thr,
-                                               int32_t* __restrict__ counts, double* __restrict__ errsums) {
-    __shared__ double s_err[HB][4];
-    __shared__ int s_cnt[HB][4];
+template <int HB, int PPL, int WAVES>
+__device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
+                                                 MatchChunk<PPL, WAVES>& m, const double (*s_F)[9], double rcut,
+                                                 int h0, int H, int32_t* __restrict__ counts,
+                                                 double* __restrict__ errsums, double (*s_err)[WAVES],
+                                                 int (*s_cnt)[WAVES]) {
+    constexpr int THREADS = 64 * WAVES;
     const int tid = threadIdx.x;
-    const int h0 = blockIdx.x * HB;
-
     double es[HB];
     int cnt[HB];  // wave-uniform: ballot popcounts
 #pragma unroll
     for (int j = 0; j < HB; ++j) { es[j] = 0.0; cnt[j] = 0; }
 
-    const double nan = __builtin_nan("");
-    for (int base = 0; base < N; base += 256 * PPL) {
-        double a0[PPL], a1[PPL], b0[PPL], b1[PPL];
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) {
-            const int i = base + k * 256 + tid;
-            const bool ok = i < N;
-            const double2 a = ok ? p0[i] : make_double2(nan, nan);  // NaN residual: never an inlier
-            const double2 b = ok ? p1[i] : make_double2(nan, nan);
-            a0[k] = a.x; a1[k] = a.y; b0[k] = b.x; b1[k] = b.y;
-        }
+    // m holds the first chunk on entry and is refilled for the following ones
+    for (int base = 0; base < N; base += THREADS * PPL) {
+        if (base > 0) m.load(p0, p1, N, base);
 #pragma unroll
         for (int j = 0; j < HB; ++j) {
-            const int h = min(h0 + j, H - 1);  // uniform; surplus slots rescore the last hypothesis and are dropped
-            const double* __restrict__ F = Fall + (size_t)h * 9;
-            const double f00 = F[0], f01 = F[1], f02 = F[2], f10 = F[3], f11 = F[4], f12 = F[5], f20 = F[6],
-                         f21 = F[7], f22 = F[8];
+            // keep each hypothesis' F loads next to their use: hoisting all of them costs 144 registers
+            asm volatile("" ::: "memory");
+            const double f00 = s_F[j][0], f01 = s_F[j][1], f02 = s_F[j][2], f10 = s_F[j][3], f11 = s_F[j][4],
+                         f12 = s_F[j][5], f20 = s_F[j][6], f21 = s_F[j][7], f22 = s_F[j][8];
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                const double l0 = fma(b0[k], f00, fma(b1[k], f10, f20));
-                const double l1 = fma(b0[k], f01, fma(b1[k], f11, f21));
-                const double l2 = fma(b0[k], f02, fma(b1[k], f12, f22));
-                const double r = fma(l0, a0[k], fma(l1, a1[k], l2));
-                const double err = r * r;
-                const bool in = err < thr;
-                cnt[j] += __popcll(__ballot(in));
-                es[j] += in ? err : 0.0;
+                const double l0 = fma(m.b0[k], f00, fma(m.b1[k], f10, f20));
+                const double l1 = fma(m.b0[k], f01, fma(m.b1[k], f11, f21));
+                const double l2 = fma(m.b0[k], f02, fma(m.b1[k], f12, f22));
+                const double r = fma(l0, m.a0[k], fma(l1, m.a1[k], l2));
+                // fl(r*r) < thr  <=>  |r| < rcut (rcut: the smallest double whose rounded square reaches thr)
+                const bool lt = fabs(r) < rcut;
+                cnt[j] += __popcll(__ballot(lt) & m.livemask[k]);
+                const double rm = (lt && m.live[k]) ? r : 0.0;
+                es[j] = fma(rm, rm, es[j]);
             }
         }
     }
-
+    SLAM_STAMP(4);
     const int wave = tid >> 6, lane = tid & 63;
+    static_assert(HB == 8, "the wave reduction handles eight hypotheses at a time");
+    {
+        const double s = wave_sum8_f64(es);
+        if (lane < 8) s_err[wave_sum8_slot(lane)][wave] = s;
+        if (lane == 0) {
 #pragma unroll
-    for (int j = 0; j < HB; ++j) {
-        const double s = wave_sum_f64(es[j]);
-        if (lane == 0) { s_err[j][wave] = s; s_cnt[j][wave] = cnt[j]; }
+            for (int j = 0; j < HB; ++j) s_cnt[j][wave] = cnt[j];
+        }
     }
     __syncthreads();
+    SLAM_STAMP(5);
     if (tid < HB && h0 + tid < H) {
-        counts[h0 + tid] = s_cnt[tid][0] + s_cnt[tid][1] + s_cnt[tid][2] + s_cnt[tid][3];
-        errsums[h0 + tid] = ((s_err[tid][0] + s_err[tid][1]) + s_err[tid][2]) + s_err[tid][3];
+        int c = 0;
+        double e = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { c += s_cnt[tid][w]; e += s_err[tid][w]; }
+        counts[h0 + tid] = c;
+        errsums[h0 + tid] = e;
     }
+}
+
+// K2 standalone: F read from memory (large H, after k_solve)
+template <int HB, int PPL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 32 / WAVES) void k_score(const double2* __restrict__ p0, const double2* __restrict__ p1,
+                                                      int N, const double* __restrict__ Fall, int H, double rcut,
+                                                      int32_t* __restrict__ counts, double* __restrict__ errsums) {
+    __shared__ double s_F[HB][9];
+    __shared__ double s_err[HB][WAVES];
+    __shared__ int s_cnt[HB][WAVES];
+    const int h0 = blockIdx.x * HB;
+    MatchChunk<PPL, WAVES> first;
+    first.load(p0, p1, N, 0);
+    if (threadIdx.x < HB * 9) {
+        const int h = min(h0 + (int)threadIdx.x / 9, H - 1);  // surplus slots rescore the last hypothesis; dropped
+        s_F[threadIdx.x / 9][threadIdx.x % 9] = Fall[(size_t)h * 9 + threadIdx.x % 9];
+    }
+    __syncthreads();
+    score_hypotheses<HB, PPL, WAVES>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
+}
+
+// K1+K2 fused for small H.  A workgroup owns WAVES hypotheses:
+//   1. every wave draws the index set of one hypothesis (wave-parallel draw) and starts loading its share of the
+//      first chunk of matches;
+//   2. lanes 0..WAVES-1 of wave 0 solve one hypothesis each (the same single-lane arithmetic as k_solve, so F is
+//      bit-identical to the split path); the other waves wait with their matches already in registers;
+//   3. the workgroup scores its hypotheses.
+// One launch and no round trip of F through memory between solve and score.
+// workgroup barrier that waits for this wave's LDS traffic only: global loads stay in flight across it
+__device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int HB, int PPL, int WAVES, int SAMPLER>
+__global__ __launch_bounds__(64 * WAVES) void k_ransac(
+    const double2* __restrict__ p0, const double2* __restrict__ p1, int N, const int32_t* __restrict__ idx_in,
+    uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw, int64_t raw_it0, double rcut,
+    double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags) {
+    static_assert(HB <= WAVES && HB <= 64, "one sampling wave and one solving lane per hypothesis");
+    __shared__ double s_F[HB][9];
+    __shared__ double s_err[HB][WAVES];
+    __shared__ int s_cnt[HB][WAVES];
+    __shared__ int32_t s_sel[HB][8];
+    __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * HB : 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int h0 = blockIdx.x * HB;
+    SLAM_STAMP(0);
+    // the sampler's word is requested first: loads return in order, so it must not queue behind the matches
+    const int hs = min(h0 + min(wave, HB - 1), H - 1);  // surplus waves redo a hypothesis; their results are dropped
+    uint32_t word = 0;
+    if (SAMPLER == SLAM_SAMPLER_CPYTHON) word = raw[(size_t)(it0 + hs - raw_it0) * SLAM_RAW_WORDS + lane];
+    asm volatile("" ::: "memory");  // keep the word's load ahead of the matches' loads
+    MatchChunk<PPL, WAVES> first;
+    first.load(p0, p1, N, 0);  // stays in flight through the sample and solve phases
+    asm volatile("" : "+v"(word));  // the word is consumed here (waits for the oldest load only); nothing sinks past
+    if (wave < HB) {
+        int32_t sel[8];
+        const bool ok = indices_for_wave<SAMPLER>(hs, N, word, idx_in, seed, it0, raw, raw_it0,
+                                                  s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * wave : 0), sel);
+        if (lane == 0) {
+            if (!ok) atomicOr(&flags[0], 1);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_sel[wave][q] = sel[q];
+        }
+    }
+    barrier_lds_only();
+    SLAM_STAMP(1);
+    if (tid < HB) {
+        int32_t sel[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sel[q] = s_sel[tid][q];
+        double F[9];
+        solve_from_indices(p0, p1, N, sel, F);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_F[tid][i] = F[i];
+        if (h0 + tid < H) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Fout[(size_t)(h0 + tid) * 9 + i] = F[i];
+        }
+    }
+    SLAM_STAMP(2);
+    barrier_lds_only();
+    SLAM_STAMP(3);
+    score_hypotheses<HB, PPL, WAVES>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -264,44 +525,60 @@ __device__ __forceinline__ bool better(const Best& x, const Best& y) {  // x bea
     return x.index < y.index;
 }
 
+__device__ __forceinline__ Best wave_best(Best b) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        Best o;
+        o.count = __shfl_xor(b.count, m, 64);
+        o.index = __shfl_xor(b.index, m, 64);
+        o.errsum = __shfl_xor(b.errsum, m, 64);
+        if (better(o, b)) b = o;
+    }
+    return b;
+}
+
 __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
                                                  const double* __restrict__ Fall, int H, int64_t it0,
                                                  const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
-                                                 double thr, double* __restrict__ record, uint8_t* __restrict__ mask) {
-    __shared__ Best s_best[1024];
+                                                 double rcut, double* __restrict__ record, uint8_t* __restrict__ mask) {
+    __shared__ Best s_best[16];
     const int tid = threadIdx.x;
+    // the winner's mask needs every match: fetch this thread's first matches while the reduction runs
+    const int i0 = tid < N ? tid : N - 1;
+    const double2 a_first = p0[i0], b_first = p1[i0];
     Best b{-1, 0x7fffffff, 0.0};
     for (int h = tid; h < H; h += 1024) {
         const Best c{counts[h], h, errsums[h]};
         if (better(c, b)) b = c;
     }
-    s_best[tid] = b;
+    b = wave_best(b);
+    if ((tid & 63) == 0) s_best[tid >> 6] = b;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) {
-            const Best o = s_best[tid + s];
-            if (better(o, s_best[tid])) s_best[tid] = o;
-        }
-        __syncthreads();
+    Best w = s_best[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+        const Best o = s_best[q];
+        if (better(o, w)) w = o;
     }
-    const Best w = s_best[0];
     const double* F = Fall + (size_t)w.index * 9;
+    const double f00 = F[0], f01 = F[1], f02 = F[2], f10 = F[3], f11 = F[4], f12 = F[5], f20 = F[6], f21 = F[7],
+                 f22 = F[8];
     if (tid == 0) {
         record[SLAM_REC_COUNT] = (double)w.count;
         record[SLAM_REC_ERRSUM] = w.errsum;
         record[SLAM_REC_INDEX] = (double)(it0 + w.index);
+        record[SLAM_REC_F + 0] = f00; record[SLAM_REC_F + 1] = f01; record[SLAM_REC_F + 2] = f02;
+        record[SLAM_REC_F + 3] = f10; record[SLAM_REC_F + 4] = f11; record[SLAM_REC_F + 5] = f12;
+        record[SLAM_REC_F + 6] = f20; record[SLAM_REC_F + 7] = f21; record[SLAM_REC_F + 8] = f22;
     }
-    if (tid < 9) record[SLAM_REC_F + tid] = F[tid];
     if (mask) {
-        const double f00 = F[0], f01 = F[1], f02 = F[2], f10 = F[3], f11 = F[4], f12 = F[5], f20 = F[6], f21 = F[7],
-                     f22 = F[8];
         for (int i = tid; i < N; i += 1024) {
-            const double2 a = p0[i], bb = p1[i];
+            const double2 a = (i == tid) ? a_first : p0[i], bb = (i == tid) ? b_first : p1[i];
             const double l0 = fma(bb.x, f00, fma(bb.y, f10, f20));
             const double l1 = fma(bb.x, f01, fma(bb.y, f11, f21));
             const double l2 = fma(bb.x, f02, fma(bb.y, f12, f22));
             const double r = fma(l0, a.x, fma(l1, a.y, l2));
-            mask[i] = (r * r < thr) ? 1 : 0;
+            mask[i] = (fabs(r) < rcut) ? 1 : 0;  // same predicate as the scoring kernels
         }
     }
 }

@@ -1,5 +1,7 @@
 // libslam_amd.so — host side of the C ABI declared in include/slam_amd.h (gfx950 only).
 #include <algorithm>
+#include <cstdlib>
+#include <limits>
 #include <cmath>
 #include <new>
 #include <thread>
@@ -286,15 +288,63 @@ extern "C" int slam_sample_indices(slam_ctx* ctx, int kind, uint64_t seed, int64
 // ================================================================================================
 // RANSAC
 // ================================================================================================
-template <int HB>
-static int launch_score_hb(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const double* F, int H,
-                           double thr, int32_t* counts, double* errsums) {
-    const dim3 grid((H + HB - 1) / HB), block(256);
-    // matches per lane and chunk: a function of N only, so that a hypothesis' errsum never depends on H or on
-    // how the hypotheses are spread over workgroups and GPUs
-    if (N <= 256) return slam_launch(ctx, SLAM_K_SCORE, k_score<HB, 1>, grid, block, 0, p0, p1, N, F, H, thr, counts, errsums);
-    if (N <= 1024) return slam_launch(ctx, SLAM_K_SCORE, k_score<HB, 4>, grid, block, 0, p0, p1, N, F, H, thr, counts, errsums);
-    return slam_launch(ctx, SLAM_K_SCORE, k_score<HB, 16>, grid, block, 0, p0, p1, N, F, H, thr, counts, errsums);
+// Smallest double c >= 0 with fl(c*c) >= thr: then fl(r*r) < thr  <=>  |r| < c for every double r, because the
+// correctly rounded square is a non-decreasing function of |r|.  thr <= 0 gives 0 (nothing is below it).
+static double square_cutoff(double thr) {
+    if (!(thr > 0.0)) return 0.0;
+    if (std::isinf(thr)) return thr;
+    double c = std::sqrt(thr);
+    while (c * c >= thr && c > 0.0) c = std::nextafter(c, 0.0);              // now fl(c*c) < thr
+    while (c * c < thr) c = std::nextafter(c, std::numeric_limits<double>::infinity());
+    return c;
+}
+
+// Workgroup shape (waves, matches per lane and chunk) is a function of N only, so that a hypothesis' errsum never
+// depends on H or on how the hypotheses are spread over kernels, workgroups and GPUs.
+//   8 waves; 1, 4 or 8 matches per lane and chunk for N <= 512, <= 2048, larger
+#define SLAM_HB 8
+#define SLAM_DISPATCH_SHAPE(N, CALL)             \
+    do {                                         \
+        if ((N) <= 512) { CALL(1, 8); }          \
+        else if ((N) <= 2048) { CALL(4, 8); }    \
+        else { CALL(8, 8); }                     \
+    } while (0)
+
+// small H: one fused launch
+template <int SAMPLER>
+static int launch_fused(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
+                        int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
+    const dim3 grid((H + SLAM_HB - 1) / SLAM_HB);
+    const uint32_t* raw = (const uint32_t*)ctx->raw.p;
+    int32_t* flags = (int32_t*)ctx->flags.p;
+#define SLAM_CALL(PPL, WAVES)                                                                                         \
+    return slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, WAVES, SAMPLER>, grid, dim3(64 * WAVES), 0, p0, p1, N, \
+                       d_idx, seed, it0, H, raw, ctx->raw_it0, thr, F, counts, errsums, flags)
+    SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
+#undef SLAM_CALL
+}
+
+// large H: a lane per hypothesis for the solve, then the scoring kernel
+template <int SAMPLER>
+static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
+                        int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SAMPLER>, dim3((H + 63) / 64), dim3(64), 0, p0, p1, N, d_idx, seed, it0,
+                         H, (const uint32_t*)ctx->raw.p, ctx->raw_it0, F, (int32_t*)ctx->flags.p));
+    const dim3 grid((H + SLAM_HB - 1) / SLAM_HB);
+#define SLAM_CALL(PPL, WAVES)                                                                                        \
+    return slam_launch(ctx, SLAM_K_SCORE, k_score<SLAM_HB, PPL, WAVES>, grid, dim3(64 * WAVES), 0, p0, p1, N,         \
+                       (const double*)F, H, thr, counts, errsums)
+    SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
+#undef SLAM_CALL
+}
+
+#define SLAM_FUSED_MAX_H 4096
+
+template <int SAMPLER>
+static int launch_ransac(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
+                         int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
+    if (H <= SLAM_FUSED_MAX_H) return launch_fused<SAMPLER>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
+    return launch_split<SAMPLER>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
 }
 
 static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
@@ -304,31 +354,22 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");          // reference: src/epipolar.py:60
     SLAM_REQUIRE(ctx, H >= 1 && it0 >= 0, "H < 1 or it0 < 0");
     SLAM_REQUIRE(ctx, d_idx || sampler == SLAM_SAMPLER_CPYTHON || sampler == SLAM_SAMPLER_COUNTER, "unknown sampler");
+    SLAM_REQUIRE(ctx, !d_idx || ((uintptr_t)d_idx & 15) == 0, "idx must be 16-byte aligned");
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
     if (!d_F_all) { SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)H * 9 * sizeof(double))); d_F_all = (double*)ctx->F.p; }
     if (!d_counts) { SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t))); d_counts = (int32_t*)ctx->counts.p; }
     if (!d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double))); d_errsums = (double*)ctx->errsums.p; }
     const double2* p0 = (const double2*)d_p0;
     const double2* p1 = (const double2*)d_p1;
-    int32_t* flags = (int32_t*)ctx->flags.p;
-    const dim3 sgrid((H + 63) / 64), sblock(64);
+    thr = square_cutoff(thr);  // from here on the threshold is the cutoff on |r|
     if (d_idx) {
-        SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<-1>, sgrid, sblock, 0, p0, p1, N, d_idx, (int32_t*)nullptr, seed,
-                             it0, H, (const uint32_t*)nullptr, (int64_t)0, d_F_all, flags));
+        SLAM_TRY(launch_ransac<-1>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
     } else if (sampler == SLAM_SAMPLER_CPYTHON) {
         SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));
-        SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SLAM_SAMPLER_CPYTHON>, sgrid, sblock, 0, p0, p1, N,
-                             (const int32_t*)nullptr, (int32_t*)nullptr, seed, it0, H, (const uint32_t*)ctx->raw.p,
-                             ctx->raw_it0, d_F_all, flags));
+        SLAM_TRY(launch_ransac<SLAM_SAMPLER_CPYTHON>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
     } else {
-        SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SLAM_SAMPLER_COUNTER>, sgrid, sblock, 0, p0, p1, N,
-                             (const int32_t*)nullptr, (int32_t*)nullptr, seed, it0, H, (const uint32_t*)nullptr,
-                             (int64_t)0, d_F_all, flags));
+        SLAM_TRY(launch_ransac<SLAM_SAMPLER_COUNTER>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
     }
-    if (H >= 8192)
-        SLAM_TRY(launch_score_hb<8>(ctx, p0, p1, N, d_F_all, H, thr, d_counts, d_errsums));
-    else
-        SLAM_TRY(launch_score_hb<4>(ctx, p0, p1, N, d_F_all, H, thr, d_counts, d_errsums));
     SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select, dim3(1), dim3(1024), 0, (const int32_t*)d_counts,
                          (const double*)d_errsums, (const double*)d_F_all, H, it0, p0, p1, N, thr, d_record, d_mask));
     return SLAM_OK;
@@ -416,8 +457,8 @@ extern "C" int slam_eightpoint(slam_ctx* ctx, const double* p0, const double* p1
         SLAM_TRY(slam_reserve(ctx, ctx->idx, sizeof iota));
         SLAM_HIP(ctx, hipMemcpyAsync(ctx->idx.p, iota, sizeof iota, hipMemcpyHostToDevice, ctx->stream));
         SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<-1>, dim3(1), dim3(64), 0, (const double2*)d0, (const double2*)d1, 8,
-                             (const int32_t*)ctx->idx.p, (int32_t*)nullptr, (uint64_t)0, (int64_t)0, 1,
-                             (const uint32_t*)nullptr, (int64_t)0, dF, (int32_t*)ctx->flags.p));
+                             (const int32_t*)ctx->idx.p, (uint64_t)0, (int64_t)0, 1, (const uint32_t*)nullptr, (int64_t)0,
+                             dF, (int32_t*)ctx->flags.p));
     } else {
         SLAM_TRY(slam_launch(ctx, -1, k_eightpoint_general, dim3(1), dim3(64), 0, (const double2*)d0, (const double2*)d1,
                              M, dF));
@@ -632,3 +673,12 @@ extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* p
     if (winner) *winner = *(const int32_t*)(hs + 60);
     return SLAM_OK;
 }
+
+#ifdef SLAM_STAMPS
+// diagnostic build only (never declared in the public header)
+extern "C" int slam_debug_stamps(slam_ctx* ctx, long long* out, int n) {
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(slamk::g_stamps), sizeof(long long) * (size_t)n));
+    return SLAM_OK;
+}
+#endif

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the fused RANSAC kernel from the diagnostic (stamped) build: SLAM_AMD_LIB points at it."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slam_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libslam_amd_stamps.so")
+import torch  # noqa: E402
+from slam_amd import pipeline, synth  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+ctx = _lib.Context(0)
+lib = ctx.lib
+dev = torch.device("cuda", 0)
+pair = synth.make_pair(N, 0.3, seed=2)
+n0, _ = pipeline.normalize_points(pair["pts0"], ctx=ctx)
+n1, _ = pipeline.normalize_points(pair["pts1"], ctx=ctx)
+d_p0, d_p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+d_rec = torch.zeros(12, dtype=torch.float64, device=dev)
+torch.cuda.synchronize()
+for _ in range(20):
+    ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N, None, 0, _lib.SEED_BASE, 0, H, 0.005,
+                                    d_rec.data_ptr(), None, None, None, None))
+nb = min(4096, (H + 7) // 8)
+out = np.zeros(nb * 8, dtype=np.int64)
+lib.slam_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+ctx.check(lib.slam_debug_stamps(ctx.handle, out.ctypes.data, nb * 8))
+st = out.reshape(nb, 8)[:, :6].astype(np.float64)
+t0 = st[:, 0].min()
+names = ["sample", "solve", "barrier", "score", "reduce"]
+d = np.diff(st, axis=1)
+print(f"N={N} H={H} blocks={nb}; cycles (shader clock) median over workgroups")
+for i, nme in enumerate(names):
+    print(f"  {nme:8s} median {np.median(d[:, i]):9.0f}  max {d[:, i].max():9.0f}")
+print(f"  start spread {np.ptp(st[:, 0]):.0f}  end-to-end {st[:, 5].max() - t0:.0f} cycles")

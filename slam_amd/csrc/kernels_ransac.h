@@ -153,34 +153,37 @@ __device__ __forceinline__ bool sample_counter8(uint64_t seed, uint64_t it, int 
 // A word is dropped as a repeat exactly when an EARLIER in-range word has the same value, so acceptance can be
 // decided for all lanes at once.  Only the first 16 in-range words are considered; if they hold fewer than 8
 // distinct values (or the 64 words run out) the caller falls back to the sequential walk.
-// All 64 lanes must be active and pass the same arguments apart from `word`.  sel[] is wave-uniform.
+// All 64 lanes must be active and pass the same arguments apart from `word`.  The indices go to LDS (out[0..7]).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool select8_from_words(uint32_t word, int N, int32_t (&sel)[8]) {
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+
+// scratch: 16 LDS words private to the calling wave; out: 8 LDS words that receive the indices
+__device__ __forceinline__ bool select8_from_words(uint32_t word, int N, int32_t* scratch, int32_t* out) {
     const int lane = threadIdx.x & 63;
     const int32_t r = (int32_t)(word >> __clz((uint32_t)N));
     const bool valid = r < N;
-    unsigned long long vmask = __ballot(valid);
-    const int my_rank = __popcll(vmask & ((1ull << lane) - 1ull));  // in-range words before this lane
+    const unsigned long long vmask = __ballot(valid);
+    const int my_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(vmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vmask, 0));
+    const int nvalid = min((int)__popcll(vmask), 16);
+    // compact the first 16 in-range values into lanes 0..15 (through LDS; same-wave LDS traffic is ordered)
+    if (valid && my_rank < 16) scratch[my_rank] = r;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int32_t c = scratch[lane & 15];
+    // lane q < 16 repeats an earlier value iff c_q == c_{q-k} for some 1 <= k <= q: rotate the row of 16 by k
     bool repeat = false;
-    unsigned long long rest = vmask;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        if (rest) {  // wave-uniform
-            const int src = __ffsll((long long)rest) - 1;
-            rest &= rest - 1ull;
-            const int32_t rq = __builtin_amdgcn_readlane(r, src);
-            repeat |= valid && (q < my_rank) && (rq == r);
-        }
-    }
-    unsigned long long amask = __ballot(valid && !repeat && my_rank < 16);
-    if (__popcll(amask) < 8) return false;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int src = __ffsll((long long)amask) - 1;
-        amask &= amask - 1ull;
-        sel[q] = __builtin_amdgcn_readlane(r, src);
-    }
-    return true;
+    const int q = lane & 15;
+    // (the rotation runs with every lane active: a DPP read from a disabled lane returns nothing)
+#define SLAM_ROT(k) { const int o_ = dpp_i32<0x120 + (k)>(c); repeat |= ((k) <= q) & (o_ == c); }  // row_ror:k: lane q-k
+    SLAM_ROT(1) SLAM_ROT(2) SLAM_ROT(3) SLAM_ROT(4) SLAM_ROT(5) SLAM_ROT(6) SLAM_ROT(7) SLAM_ROT(8)
+    SLAM_ROT(9) SLAM_ROT(10) SLAM_ROT(11) SLAM_ROT(12) SLAM_ROT(13) SLAM_ROT(14) SLAM_ROT(15)
+#undef SLAM_ROT
+    const bool accepted = (lane < nvalid) && !repeat;
+    const unsigned long long amask = __ballot(accepted);
+    const int arank = __builtin_amdgcn_mbcnt_lo((unsigned)amask, 0);  // accepted lanes are all below 16
+    if (accepted && arank < 8) out[arank] = c;
+    return __popcll(amask) >= 8;
 }
 
 // sequential walk over a lane-private copy of the stream (used when the wave-parallel draw does not apply)
@@ -219,30 +222,30 @@ __device__ __forceinline__ bool sample_cpython_seq(const uint32_t* row, int N, i
     return !overflow;
 }
 
-// One iteration's 8 indices for a whole wave (wave-uniform result).  SAMPLER: -1 = given, else SLAM_SAMPLER_*.
+// One iteration's 8 indices drawn by a whole wave into LDS (out[0..7]).  SAMPLER: -1 = given, else SLAM_SAMPLER_*.
 // word0: this lane's word of the iteration's MT19937 row (CPython sampler only).
-// pool: LDS bytes [SLAM_POOL_MAX] private to this wave.
+// pool: LDS bytes [SLAM_POOL_MAX] and scratch: 16 LDS words, both private to this wave.
 template <int SAMPLER>
 __device__ __forceinline__ bool indices_for_wave(int h, int N, uint32_t word0, const int32_t* __restrict__ idx_in,
                                                  uint64_t seed, int64_t it0, const uint32_t* __restrict__ raw,
-                                                 int64_t raw_it0, uint8_t* pool, int32_t (&sel)[8]) {
+                                                 int64_t raw_it0, uint8_t* pool, int32_t* scratch, int32_t* out) {
     const int lane = threadIdx.x & 63;
     if (SAMPLER < 0) {
-        const int32_t v = idx_in[(size_t)h * 8 + (lane & 7)];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sel[q] = __builtin_amdgcn_readlane(v, q);
+        if (lane < 8) out[lane] = idx_in[(size_t)h * 8 + lane];
         return true;
     } else if (SAMPLER == SLAM_SAMPLER_CPYTHON) {
         const uint32_t* row = raw + (size_t)(it0 + h - raw_it0) * SLAM_RAW_WORDS;
         if (N > sample_setsize(8)) {  // set path of random.sample; word0 = row[lane], loaded by the caller
-            if (select8_from_words(word0, N, sel)) return true;
+            if (select8_from_words(word0, N, scratch, out)) return true;
         }
         // pool path (N <= 85) or a draw that needs more than the first 16 in-range words: sequential, on lane 0
-        int32_t out[8];
         bool ok = true;
-        if (lane == 0) ok = sample_cpython_seq(row, N, 8, out, pool, 0, 1);
+        if (lane == 0) {
+            int32_t sel[8];
+            ok = sample_cpython_seq(row, N, 8, sel, pool, 0, 1);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sel[q] = __builtin_amdgcn_readlane(out[q], 0);
+            for (int q = 0; q < 8; ++q) out[q] = sel[q];
+        }
         return __builtin_amdgcn_readlane((int)ok, 0) != 0;
     } else {
         uint32_t w[4];
@@ -250,8 +253,14 @@ __device__ __forceinline__ bool indices_for_wave(int h, int N, uint32_t word0, c
                       (uint32_t)seed, (uint32_t)(seed >> 32), w);
         const int u = lane & 3;
         const uint32_t word = u == 0 ? w[0] : (u == 1 ? w[1] : (u == 2 ? w[2] : w[3]));
-        if (select8_from_words(word, N, sel)) return true;
-        return sample_counter8(seed, (uint64_t)(it0 + h), N, 8, sel);  // every lane walks the same stream
+        if (select8_from_words(word, N, scratch, out)) return true;
+        int32_t sel[8];
+        const bool ok = sample_counter8(seed, (uint64_t)(it0 + h), N, 8, sel);  // every lane walks the same stream
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] = sel[q];
+        }
+        return ok;
     }
 }
 
@@ -464,6 +473,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ransac(
     __shared__ double s_err[HB][WAVES];
     __shared__ int s_cnt[HB][WAVES];
     __shared__ int32_t s_sel[HB][8];
+    __shared__ int32_t s_scratch[HB][16];
     __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * HB : 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int h0 = blockIdx.x * HB;
@@ -477,14 +487,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_ransac(
     first.load(p0, p1, N, 0);  // stays in flight through the sample and solve phases
     asm volatile("" : "+v"(word));  // the word is consumed here (waits for the oldest load only); nothing sinks past
     if (wave < HB) {
-        int32_t sel[8];
         const bool ok = indices_for_wave<SAMPLER>(hs, N, word, idx_in, seed, it0, raw, raw_it0,
-                                                  s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * wave : 0), sel);
-        if (lane == 0) {
-            if (!ok) atomicOr(&flags[0], 1);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s_sel[wave][q] = sel[q];
-        }
+                                                  s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * wave : 0),
+                                                  s_scratch[wave], s_sel[wave]);
+        if (!ok && lane == 0) atomicOr(&flags[0], 1);
     }
     barrier_lds_only();
     SLAM_STAMP(1);

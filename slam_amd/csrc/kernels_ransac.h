@@ -386,6 +386,7 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
 #pragma unroll
     for (int j = 0; j < HB; ++j) { es[j] = 0.0; cnt[j] = 0; }
 
+    const unsigned long long full_exec = __ballot(true);  // every lane of the workgroup is active here
     // m holds the first chunk on entry and is refilled for the following ones
     for (int base = 0; base < N; base += THREADS * PPL) {
         if (base > 0) m.load(p0, p1, N, base);
@@ -395,17 +396,32 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
             asm volatile("" ::: "memory");
             const double f00 = s_F[j][0], f01 = s_F[j][1], f02 = s_F[j][2], f10 = s_F[j][3], f11 = s_F[j][4],
                          f12 = s_F[j][5], f20 = s_F[j][6], f21 = s_F[j][7], f22 = s_F[j][8];
+            // residuals of the PPL matches first (independent chains), then the masked accumulation
+            double r[PPL];
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
                 const double l0 = fma(m.b0[k], f00, fma(m.b1[k], f10, f20));
                 const double l1 = fma(m.b0[k], f01, fma(m.b1[k], f11, f21));
                 const double l2 = fma(m.b0[k], f02, fma(m.b1[k], f12, f22));
-                const double r = fma(l0, m.a0[k], fma(l1, m.a1[k], l2));
-                // fl(r*r) < thr  <=>  |r| < rcut (rcut: the smallest double whose rounded square reaches thr)
-                const bool lt = fabs(r) < rcut;
-                cnt[j] += __popcll(__ballot(lt) & m.livemask[k]);
-                const double rm = (lt && m.live[k]) ? r : 0.0;
-                es[j] = fma(rm, rm, es[j]);
+                r[k] = fma(l0, m.a0[k], fma(l1, m.a1[k], l2));
+            }
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                // fl(r*r) < thr  <=>  |r| < rcut (rcut: the smallest double whose rounded square reaches thr).
+                // The compare writes the execution mask itself, so the inlier lanes alone accumulate r*r and the
+                // mask's population count is the inlier count: no select instructions.
+                int n_in;
+                unsigned long long lt_mask;
+                asm volatile(
+                    "v_cmpx_lt_f64_e64 %[lt], |%[r]|, %[rc]\n\t"
+                    "s_and_b64 exec, exec, %[live]\n\t"
+                    "s_bcnt1_i32_b64 %[n], exec\n\t"
+                    "v_fma_f64 %[es], %[r], %[r], %[es]\n\t"
+                    "s_mov_b64 exec, %[full]"
+                    : [es] "+v"(es[j]), [n] "=&s"(n_in), [lt] "=&s"(lt_mask)  // written before the inputs are all read
+                    : [r] "v"(r[k]), [rc] "s"(rcut), [live] "s"(m.livemask[k]), [full] "s"(full_exec)
+                    : "scc");
+                cnt[j] += n_in;
             }
         }
     }

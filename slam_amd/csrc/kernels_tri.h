@@ -33,7 +33,7 @@ enum {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, const double* __restrict__ P1, double u0,
                                                 double v0, double u1, double v1, double (&X)[3]) {
-    double D[4][4], V[4][4], m[4];
+    double D[4][4], m[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         D[0][j] = fma(v0, P0[8 + j], -P0[4 + j]);
@@ -50,24 +50,12 @@ __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, c
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) D[i][j] *= im[j];
-    jacobi_svd<4, 4>(D, V, 30);
-    double n2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) n2[j] = D[0][j] * D[0][j] + D[1][j] * D[1][j] + D[2][j] * D[2][j] + D[3][j] * D[3][j];
-    int least = 0;
-    double best = n2[0];
-#pragma unroll
-    for (int j = 1; j < 4; ++j) {
-        const bool lt = n2[j] < best;
-        best = lt ? n2[j] : best;
-        least = lt ? j : least;
-    }
+    // polished until further rotations would turn y by less than 1e-12 rad (the points are compared to 1e-5)
+    double yv[4];
+    least_right_vector_4x4(D, 1e-12, yv);
     double Y[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double y = least == 0 ? V[i][0] : (least == 1 ? V[i][1] : (least == 2 ? V[i][2] : V[i][3]));
-        Y[i] = m[i] * y;
-    }
+    for (int i = 0; i < 4; ++i) Y[i] = m[i] * yv[i];
     X[0] = Y[0] / Y[3];
     X[1] = Y[1] / Y[3];
     X[2] = Y[2] / Y[3];

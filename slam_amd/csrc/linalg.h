@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace slamk {
 
 // Plane rotation that orthogonalises two columns with squared norms a, b and inner product c.
@@ -29,51 +31,94 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // One-sided (Hestenes) Jacobi sweeps on an M x N matrix held as A[row][col], accumulating the rotations into V
 // (which the caller initialises, normally to the identity).
-// On return A = A_in * R and V = V_in * R for the accumulated rotation R; the columns of A are mutually orthogonal
-// (column j = sigma_j u_j when V_in was the identity).
-// Columns whose squared norm is below 1e-32 ||A||_F^2 are treated as converged (rounding-level null columns).
-template <int M, int N>
-__device__ __forceinline__ void jacobi_sweeps(double (&A)[M][N], double (&V)[N][N], int max_sweeps) {
+// On return A = A_in * R and V = V_in * R for the accumulated rotation R.
+//
+// A pair of columns with squared norms a, b and inner product c is rotated while it is not orthogonal to rounding
+// (c^2 > 1e-30 a b) AND the rotation would still turn the right vectors by more than angle_tol (|c| > angle_tol
+// |a - b|, since the angle is about c / (b - a)).  Columns whose squared norm is below 1e-32 ||A||_F^2 are
+// treated as converged (rounding-level null columns).
+//
+// LAST_ONLY = false: every pair must converge; the columns of A end up mutually orthogonal (column j = sigma_j u_j
+//   when V_in was the identity).
+// LAST_ONLY = true: only the LAST column has to become orthogonal to the others, which makes V's last column a
+//   right singular vector (the least one when the caller started near it); the other pairs are rotated only
+//   while that is not yet the case, as part of the same cyclic sweep.  Lanes with `full` set (no good start)
+//   still converge every pair.
+template <int M, int N, bool LAST_ONLY>
+__device__ __forceinline__ void jacobi_sweeps(double (&A)[M][N], double (&V)[N][N], int max_sweeps, double angle_tol,
+                                              bool full = false) {
     double fro2 = 0.0;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) fro2 = fma(A[i][j], A[i][j], fro2);
     const double floor2 = fro2 * 1e-32;
+
+    auto rotate_pair = [&](auto P, auto Q, bool allowed) -> bool {
+        constexpr int p = decltype(P)::value, q = decltype(Q)::value;
+        double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            a = fma(A[i][p], A[i][p], a);
+            b = fma(A[i][q], A[i][q], b);
+            c = fma(A[i][p], A[i][q], c);
+        }
+        const bool go = allowed && (a > floor2) && (b > floor2) && (c * c > 1e-30 * (a * b)) &&
+                        (fabs(c) > angle_tol * fabs(a - b));
+        if (__any(go)) {  // wave-uniform: a converged wave only pays for the three inner products
+            double cs, sn;
+            jacobi_angle(a, b, c, cs, sn);
+            cs = go ? cs : 1.0;
+            sn = go ? sn : 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const double x = A[i][p], y = A[i][q];
+                A[i][p] = fma(cs, x, -sn * y);
+                A[i][q] = fma(sn, x, cs * y);
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double x = V[i][p], y = V[i][q];
+                V[i][p] = fma(cs, x, -sn * y);
+                V[i][q] = fma(sn, x, cs * y);
+            }
+        }
+        return go;
+    };
+
+    static_assert(N == 3 || N == 4, "pairs are enumerated by hand for 3 and 4 columns");
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         bool rotated = false;
-#pragma unroll
-        for (int p = 0; p < N - 1; ++p) {
-#pragma unroll
-            for (int q = p + 1; q < N; ++q) {
-                double a = 0.0, b = 0.0, c = 0.0;
-#pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    a = fma(A[i][p], A[i][p], a);
-                    b = fma(A[i][q], A[i][q], b);
-                    c = fma(A[i][p], A[i][q], c);
-                }
-                // rotate while the columns are not orthogonal to ~1e-15 relative
-                const bool go = (a > floor2) && (b > floor2) && (c * c > 1e-30 * (a * b));
-                if (__any(go)) {  // wave-uniform: a converged wave only pays for the three inner products
-                    double cs, sn;
-                    jacobi_angle(a, b, c, cs, sn);
-                    cs = go ? cs : 1.0;
-                    sn = go ? sn : 0.0;
-                    rotated |= go;
-#pragma unroll
-                    for (int i = 0; i < M; ++i) {
-                        const double x = A[i][p], y = A[i][q];
-                        A[i][p] = fma(cs, x, -sn * y);
-                        A[i][q] = fma(sn, x, cs * y);
-                    }
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const double x = V[i][p], y = V[i][q];
-                        V[i][p] = fma(cs, x, -sn * y);
-                        V[i][q] = fma(sn, x, cs * y);
-                    }
-                }
+        if constexpr (LAST_ONLY) {
+            // pairs with the last column first; the rest only for lanes that are not done
+            if constexpr (N == 3) {
+                rotated |= rotate_pair(I0{}, I2{}, true);
+                rotated |= rotate_pair(I1{}, I2{}, true);
+            } else {
+                rotated |= rotate_pair(I0{}, I3{}, true);
+                rotated |= rotate_pair(I1{}, I3{}, true);
+                rotated |= rotate_pair(I2{}, I3{}, true);
+            }
+            const bool more = rotated || full;
+            if (!__any(more)) break;
+            bool others = rotate_pair(I0{}, I1{}, more);
+            if constexpr (N == 4) {
+                others |= rotate_pair(I0{}, I2{}, more);
+                others |= rotate_pair(I1{}, I2{}, more);
+            }
+            rotated |= full && others;
+        } else {
+            rotated |= rotate_pair(I0{}, I1{}, true);
+            rotated |= rotate_pair(I0{}, I2{}, true);
+            if constexpr (N == 4) rotated |= rotate_pair(I0{}, I3{}, true);
+            rotated |= rotate_pair(I1{}, I2{}, true);
+            if constexpr (N == 4) {
+                rotated |= rotate_pair(I1{}, I3{}, true);
+                rotated |= rotate_pair(I2{}, I3{}, true);
             }
         }
         // leave when no lane of the wave still rotates (keeps the wave converged together)
@@ -87,7 +132,7 @@ __device__ __forceinline__ void jacobi_svd(double (&A)[M][N], double (&V)[N][N],
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    jacobi_sweeps<M, N>(A, V, max_sweeps);
+    jacobi_sweeps<M, N, false>(A, V, max_sweeps, 1e-15);
 }
 
 // Unit null vector of the 8 x 9 system  sum_r n[r] * A[r][c] = 0  for c = 0..7, where A (9 x 8) holds the
@@ -205,10 +250,19 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) B[r][c] = f[r][0] * V[0][c] + f[r][1] * V[1][c] + f[r][2] * V[2][c];
-    jacobi_sweeps<3, 3>(B, V, 30);
+    // only v3 enters the projection f (I - v3 v3^T): the third column alone has to converge (lanes without a usable
+    // estimate converge every pair and pick the smallest column below)
+    jacobi_sweeps<3, 3, true>(B, V, 30, 1e-15, !usable);
     double n2[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];
+    // ||f v|| >= sigma_3 for every unit v, so a converged third column can never be longer than another column;
+    // if it is, the start was poor and the third column settled on the wrong singular vector: converge every pair
+    if (__any(n2[2] > n2[0] || n2[2] > n2[1])) {
+        jacobi_sweeps<3, 3, false>(B, V, 30, 1e-15);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];
+    }
     // weight 0 for the column with the smallest norm (first one on ties), 1 for the others
     const bool d0 = (n2[0] <= n2[1]) && (n2[0] <= n2[2]);
     const bool d1 = !d0 && (n2[1] <= n2[2]);
@@ -222,6 +276,135 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
             for (int j = 0; j < 3; ++j) s = fma(w[j] * B[r][j], V[c][j], s);
             F[3 * r + c] = s;
         }
+}
+
+// Right singular vector of the smallest singular value of a 4 x 4 matrix A (held as A[row][col]; destroyed).
+//
+// Warm start as in rank2_project: G = A^T A; lambda = smallest root of its characteristic quartic by Newton from 0
+// (monotone from below); the largest column of adj(G - lambda I) is parallel to the wanted vector v; a Householder
+// reflector that maps a unit axis onto v supplies an orthonormal basis with v as its last column.  One-sided Jacobi
+// sweeps on A itself then polish the last column (they do not see G's squared condition number).
+// angle_tol: rotation angle below which a pair counts as converged.
+__device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double angle_tol, double (&y)[4]) {
+    double g[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j) {
+            g[i][j] = A[0][i] * A[0][j] + A[1][i] * A[1][j] + A[2][i] * A[2][j] + A[3][i] * A[3][j];
+            g[j][i] = g[i][j];
+        }
+    // 2 x 2 minors of rows (0,1) and rows (2,3) of a symmetric matrix with diagonal d0..d3
+    double s0, s1, s2, s3, s4, s5, c0, c1, c2, c3, c4, c5;
+    auto minors = [&](double d0, double d1, double d2, double d3) {
+        s0 = d0 * d1 - g[0][1] * g[0][1];
+        s1 = d0 * g[1][2] - g[0][1] * g[0][2];
+        s2 = d0 * g[1][3] - g[0][1] * g[0][3];
+        s3 = g[0][1] * g[1][2] - d1 * g[0][2];
+        s4 = g[0][1] * g[1][3] - d1 * g[0][3];
+        s5 = g[0][2] * g[1][3] - g[1][2] * g[0][3];
+        c0 = s5;
+        c1 = g[0][2] * g[2][3] - d2 * g[0][3];
+        c2 = g[0][2] * d3 - g[2][3] * g[0][3];
+        c3 = g[1][2] * g[2][3] - d2 * g[1][3];
+        c4 = g[1][2] * d3 - g[2][3] * g[1][3];
+        c5 = d2 * d3 - g[2][3] * g[2][3];
+    };
+    minors(g[0][0], g[1][1], g[2][2], g[3][3]);
+    // characteristic polynomial x^4 - k3 x^3 + k2 x^2 - k1 x + k0
+    const double k0 = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const double k1 = (g[1][1] * c5 - g[1][2] * c4 + g[1][3] * c3) + (g[0][0] * c5 - g[0][2] * c2 + g[0][3] * c1) +
+                      (g[3][3] * s0 - g[1][3] * s2 + g[0][3] * s4) + (g[2][2] * s0 - g[1][2] * s1 + g[0][2] * s3);
+    const double k2 = s0 + c5 + (g[0][0] * g[2][2] - g[0][2] * g[0][2]) + (g[0][0] * g[3][3] - g[0][3] * g[0][3]) +
+                      (g[1][1] * g[2][2] - g[1][2] * g[1][2]) + (g[1][1] * g[3][3] - g[1][3] * g[1][3]);
+    const double k3 = g[0][0] + g[1][1] + g[2][2] + g[3][3];
+    double lam = 0.0;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const double p = fma(fma(fma(lam - k3, lam, k2), lam, -k1), lam, k0);
+        const double dp = fma(fma(fma(4.0, lam, -3.0 * k3), lam, k2 + k2), lam, -k1);
+        lam = fma(-p, __builtin_amdgcn_rcp(dp), lam);  // approximate reciprocal: the iteration self-corrects
+    }
+    const double d0 = g[0][0] - lam, d1 = g[1][1] - lam, d2 = g[2][2] - lam, d3 = g[3][3] - lam;
+    minors(d0, d1, d2, d3);
+    // adjugate of the shifted matrix (symmetric): a multiple of v v^T
+    const double j00 = d1 * c5 - g[1][2] * c4 + g[1][3] * c3;
+    const double j01 = -g[0][1] * c5 + g[0][2] * c4 - g[0][3] * c3;
+    const double j02 = g[1][3] * s5 - g[2][3] * s4 + d3 * s3;
+    const double j03 = -g[1][2] * s5 + d2 * s4 - g[2][3] * s3;
+    const double j11 = d0 * c5 - g[0][2] * c2 + g[0][3] * c1;
+    const double j12 = -g[0][3] * s5 + g[2][3] * s2 - d3 * s1;
+    const double j13 = g[0][2] * s5 - d2 * s2 + g[2][3] * s1;
+    const double j22 = g[0][3] * s4 - g[1][3] * s2 + d3 * s0;
+    const double j23 = -g[0][2] * s4 + g[1][2] * s2 - g[2][3] * s0;
+    const double j33 = g[0][2] * s3 - g[1][2] * s1 + d2 * s0;
+    const double a0 = fabs(j00), a1 = fabs(j11), a2 = fabs(j22), a3 = fabs(j33);
+    const bool p0 = (a0 >= a1) && (a0 >= a2) && (a0 >= a3);
+    const bool p1 = !p0 && (a1 >= a2) && (a1 >= a3);
+    const bool p2 = !p0 && !p1 && (a2 >= a3);
+    double v[4];
+    v[0] = p0 ? j00 : p1 ? j01 : p2 ? j02 : j03;
+    v[1] = p0 ? j01 : p1 ? j11 : p2 ? j12 : j13;
+    v[2] = p0 ? j02 : p1 ? j12 : p2 ? j22 : j23;
+    v[3] = p0 ? j03 : p1 ? j13 : p2 ? j23 : j33;
+    const double vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    const bool usable = (vn2 > 0.0) && (vn2 < 1e300);  // false for NaN, zero or overflow: start from the identity
+    const double vi = rsqrt(vn2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = usable ? v[i] * vi : (i == 3 ? 1.0 : 0.0);
+    // Householder reflector H = I - w w^T / (1 + |v_k|), w = v + sign(v_k) e_k, k = largest |v_k|: column k of H is
+    // -sign(v_k) v and the other columns complete an orthonormal basis.  V = H with columns k and 3 exchanged.
+    const double q0 = fabs(v[0]), q1 = fabs(v[1]), q2 = fabs(v[2]), q3 = fabs(v[3]);
+    const bool m0 = (q0 >= q1) && (q0 >= q2) && (q0 >= q3);
+    const bool m1 = !m0 && (q1 >= q2) && (q1 >= q3);
+    const bool m2 = !m0 && !m1 && (q2 >= q3);
+    const bool m3 = !m0 && !m1 && !m2;
+    const double vk = m0 ? v[0] : m1 ? v[1] : m2 ? v[2] : v[3];
+    const double sg = vk >= 0.0 ? 1.0 : -1.0;
+    double w[4] = {v[0] + (m0 ? sg : 0.0), v[1] + (m1 ? sg : 0.0), v[2] + (m2 ? sg : 0.0), v[3] + (m3 ? sg : 0.0)};
+    const double beta = fast_rcp(1.0 + fabs(vk));
+    double V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[i][j] = fma(-beta * w[i], w[j], (i == j) ? 1.0 : 0.0);
+    // B = A H = A - beta (A w) w^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double aw = beta * (A[r][0] * w[0] + A[r][1] * w[1] + A[r][2] * w[2] + A[r][3] * w[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[r][j] = fma(-aw, w[j], A[r][j]);
+    }
+    // bring the v column (k) to position 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double ak = m0 ? A[r][0] : m1 ? A[r][1] : m2 ? A[r][2] : A[r][3];
+        const double vk_ = m0 ? V[r][0] : m1 ? V[r][1] : m2 ? V[r][2] : V[r][3];
+        const double a3_ = A[r][3], v3_ = V[r][3];
+        A[r][0] = m0 ? a3_ : A[r][0]; A[r][1] = m1 ? a3_ : A[r][1]; A[r][2] = m2 ? a3_ : A[r][2]; A[r][3] = ak;
+        V[r][0] = m0 ? v3_ : V[r][0]; V[r][1] = m1 ? v3_ : V[r][1]; V[r][2] = m2 ? v3_ : V[r][2]; V[r][3] = vk_;
+    }
+    jacobi_sweeps<4, 4, true>(A, V, 30, angle_tol, !usable);
+    double n2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n2[j] = A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j] + A[3][j] * A[3][j];
+    // a converged least column cannot be longer than any other column (||A v|| >= sigma_min for unit v); if it is,
+    // the start was poor: converge every pair and take the shortest column
+    if (__any(n2[3] > n2[0] || n2[3] > n2[1] || n2[3] > n2[2] || !usable)) {
+        jacobi_sweeps<4, 4, false>(A, V, 30, angle_tol);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n2[j] = A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j] + A[3][j] * A[3][j];
+    }
+    int least = 3;
+    double best = n2[3];
+#pragma unroll
+    for (int j = 2; j >= 0; --j) {
+        const bool lt = n2[j] < best;
+        best = lt ? n2[j] : best;
+        least = lt ? j : least;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = least == 0 ? V[i][0] : (least == 1 ? V[i][1] : (least == 2 ? V[i][2] : V[i][3]));
 }
 
 // Sum over the 64 lanes of a wave in a fixed order, without LDS traffic: xor-1 and xor-2 inside quads, then the

@@ -48,14 +48,22 @@ def main():
     ap.add_argument("--no-aux", action="store_true")
     args = ap.parse_args()
 
+    # Libraries (RCCL's start-up banner among them) write to stdout; the contract is ONE JSON line there.  Keep the
+    # real stdout aside and point descriptor 1 at stderr until the line is ready.
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): one rank per GPU over RCCL, also when there is a single rank
+    use_dist = "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -66,7 +74,7 @@ def main():
     lib = ctx.lib
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         ctx.check(lib.slam_synchronize(ctx.handle))
         torch.cuda.synchronize()
@@ -96,7 +104,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -192,7 +200,7 @@ def main():
             ctx.check(lib.slam_ransac_f_dev(ctx.handle, e_p0.data_ptr(), e_p1.data_ptr(), N3, None, _lib.SAMPLER_COUNTER,
                                             3, lo, hi - lo, _lib.DEFAULT_THRESHOLD, e_rec.data_ptr(), None, None, None, None))
             ctx.check(lib.slam_synchronize(ctx.handle))
-            if world > 1:
+            if use_dist:
                 return pipeline.allgather_winner(e_rec)              # all_gather_into_tensor on the GPU = RCCL
             return 0, e_rec.cpu().numpy()
 
@@ -203,7 +211,7 @@ def main():
             who, win = shard_step()
         barrier()
         sdt = (time.perf_counter() - t0) / 3
-        if world > 1:
+        if use_dist:
             t = torch.tensor([sdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sdt = float(t.item())
@@ -244,7 +252,7 @@ def main():
         def tri_step():
             ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0.data_ptr(), p1.data_ptr(), NT,
                                                    d_counts.data_ptr()))
-            if world > 1:   # point-sharded semantics: the four counts are summed over ranks before the winner is picked
+            if use_dist:    # point-sharded semantics: the four counts are summed over ranks before the winner is picked
                 ctx.check(lib.slam_synchronize(ctx.handle))
                 dist.all_reduce(d_counts)
                 torch.cuda.synchronize()
@@ -264,7 +272,7 @@ def main():
         ms, n = C.c_double(0), C.c_int64(0)
         ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_TRIANGULATE, C.byref(ms), C.byref(n)))
         ctx.check(lib.slam_profile_enable(ctx.handle, 0))
-        if world > 1:
+        if use_dist:
             t = torch.tensor([tdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tdt = float(t.item())
@@ -304,8 +312,9 @@ def main():
                                "reference_python_measured_in_survey": {"value": 80.0, "unit": "hypotheses/s", "cores": 1}}
 
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--tri-points", type=int, default=1 << 24)
+    ap.add_argument("--lanes", type=int, default=3, help="independent steps the library may keep in flight (1..3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true")
     args = ap.parse_args()
@@ -85,13 +86,21 @@ def main():
     n1, _ = pipeline.normalize_points(pair["pts1"], ctx=ctx)
     d_p0 = torch.from_numpy(n0).to(dev)
     d_p1 = torch.from_numpy(n1).to(dev)
-    d_rec = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
-    d_mask = torch.zeros(N_MATCHES, dtype=torch.uint8, device=dev)
+    # Successive steps are independent RANSAC problems; the library may keep up to LANES of them in flight on its
+    # internal streams (one step's selection kernel overlaps the next step's solve), each with its own outputs.
+    LANES = args.lanes
+    ctx.check(lib.slam_set_concurrency(ctx.handle, LANES))
+    recs = [torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev) for _ in range(LANES)]
+    masks = [torch.zeros(N_MATCHES, dtype=torch.uint8, device=dev) for _ in range(LANES)]
+    d_rec, d_mask = recs[0], masks[0]
     torch.cuda.synchronize()
+    calls = [0]
 
     def step():
+        k = calls[0] % LANES
+        calls[0] += 1
         rc = lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None, _lib.SAMPLER_CPYTHON,
-                                   _lib.SEED_BASE, 0, N_HYP, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(), d_mask.data_ptr(),
+                                   _lib.SEED_BASE, 0, N_HYP, _lib.DEFAULT_THRESHOLD, recs[k].data_ptr(), masks[k].data_ptr(),
                                    None, None, None)
         if rc:
             ctx.check(rc)
@@ -109,7 +118,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rec = d_rec.cpu().numpy()
+    assert all(torch.equal(r, recs[0]) for r in recs), "lanes disagree"
     value = world * N_HYP * args.steps / dt
+    # the same K steps strictly one after the other (one stream): the latency of a single call
+    ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt_serial = time.perf_counter() - t0
 
     # ---- roofline of the scoring kernel: per-launch durations from HIP events on the library's stream
     ctx.check(lib.slam_profile_enable(ctx.handle, 1))
@@ -147,6 +165,7 @@ def main():
                       "n_matches": N_MATCHES, "hypotheses": N_HYP, "outlier_fraction": OUTLIERS,
                       "sharding": "independent frame pairs per GPU, no collective"},
            "residual_evals_per_sec": value * N_MATCHES,
+           "steps_in_flight": LANES, "ms_per_step_one_stream": dt_serial / args.steps * 1e3,
            "winner": {"index": int(rec[_lib.REC_INDEX]), "inliers": int(rec[_lib.REC_COUNT])},
            "roofline": roofline}
 

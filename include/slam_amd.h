@@ -32,7 +32,7 @@ enum {
     SLAM_EINVAL = -1,      /* bad argument (NULL pointer, N < 8, H < 1, ...): the reference asserts here */
     SLAM_EHIP = -2,        /* a HIP runtime call failed */
     SLAM_ENOMEM = -3,      /* device or host allocation failed */
-    SLAM_ESAMPLER = -4,    /* the sampler ran out of pre-generated random words (see slam_sample8_cpython) */
+    SLAM_ESAMPLER = -4,    /* the sampler ran out of pre-generated random words (see slam_sample_indices) */
     SLAM_ENODEVICE = -5    /* no usable GPU */
 };
 
@@ -58,6 +58,12 @@ void slam_destroy(slam_ctx* ctx);
 const char* slam_last_error(const slam_ctx* ctx); /* ctx may be NULL: text of the last slam_create failure */
 /* use the caller's HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it */
 int slam_set_stream(slam_ctx* ctx, void* hip_stream);
+/* Number of internal streams (1..3, default 1) that successive slam_ransac_f_dev calls rotate over.  With more than
+ * one, consecutive calls may run concurrently (one call's selection overlaps the next call's solve): they must be
+ * independent of each other, use distinct output buffers, and their outputs are ready only after slam_synchronize().
+ * Ignored while a caller-supplied stream is set.  No counterpart in the reference (it is single-threaded). */
+int slam_set_concurrency(slam_ctx* ctx, int lanes);
+/* waits for everything the context has queued, on every internal stream */
 int slam_synchronize(slam_ctx* ctx);
 
 /* ---- sampler: src/epipolar.py:62,69-71 ---------------------------------------------------------- */

@@ -26,6 +26,7 @@ SIGNATURES = {
     "slam_destroy": (None, [_vp]),
     "slam_last_error": (C.c_char_p, [_vp]),
     "slam_set_stream": (_int, [_vp, _vp]),
+    "slam_set_concurrency": (_int, [_vp, _int]),
     "slam_synchronize": (_int, [_vp]),
     "slam_num_hypotheses": (_i64, [_i64, _i64]),
     "slam_sample_indices": (_int, [_vp, _int, _u64, _i64, _int, _int, _int, _vp]),

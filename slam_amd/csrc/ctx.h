@@ -26,18 +26,25 @@ struct slam_prof {
     int64_t launches[SLAM_K_COUNT] = {0, 0, 0, 0};
 };
 
+#define SLAM_LANES 3  // internal streams that independent RANSAC calls rotate over
+
 struct slam_ctx {
     int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;   // lane 0
+    hipStream_t stream = nullptr;       // the context's ordered stream: own_stream, or the caller's (slam_set_stream)
+    hipStream_t cur = nullptr;          // stream the launch helper uses right now (stream, or a lane)
+    hipStream_t lane_stream[SLAM_LANES] = {nullptr, nullptr, nullptr};
+    unsigned next_lane = 0;
+    int lanes_in_use = 1;               // slam_set_concurrency
     char err[512] = {0};
 
     // device scratch (grown on demand, never shrunk)
     slam_buf pts;       // staged (N,2)+(N,2) points of the host entry points
     slam_buf idx;       // H*8 int32
-    slam_buf F;         // H*9 f64
-    slam_buf counts;    // H int32
-    slam_buf errsums;   // H f64
+    slam_buf F;         // H*9 f64        } lane 0's hypothesis scratch
+    slam_buf counts;    // H int32        }
+    slam_buf errsums;   // H f64          }
+    slam_buf lane_F[SLAM_LANES], lane_counts[SLAM_LANES], lane_errsums[SLAM_LANES];  // lanes 1.. (index 0 unused)
     slam_buf mask;      // N u8
     slam_buf record;    // SLAM_REC_LEN f64 + flags
     slam_buf raw;       // MT19937 words [raw_n][SLAM_RAW_WORDS]
@@ -80,12 +87,20 @@ struct slam_ctx {
         if (rc_ != SLAM_OK) return rc_; \
     } while (0)
 
+// wait for everything the context has queued, on its ordered stream and on every lane
+static inline int slam_sync_all(slam_ctx* ctx) {
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < SLAM_LANES; ++l)
+        if (ctx->lane_stream[l] && ctx->lane_stream[l] != ctx->stream) SLAM_HIP(ctx, hipStreamSynchronize(ctx->lane_stream[l]));
+    return SLAM_OK;
+}
+
 // make sure b holds at least `bytes`; contents are NOT preserved
 static inline int slam_reserve(slam_ctx* ctx, slam_buf& b, size_t bytes) {
     if (bytes <= b.cap) return SLAM_OK;
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
-    // a buffer may still be in use by work queued on the stream
-    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // a buffer may still be in use by work queued on any of the context's streams
+    SLAM_TRY(slam_sync_all(ctx));
     if (b.p) SLAM_HIP(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -99,7 +114,7 @@ static inline int slam_reserve(slam_ctx* ctx, slam_buf& b, size_t bytes) {
     return SLAM_OK;
 }
 
-// Launch on the context's stream.  With profiling on, the launch carries a start/stop event pair whose
+// Launch on the context's current stream (ctx->cur).  With profiling on, the launch carries a start/stop event pair whose
 // timestamps are those of the dispatch itself, so the elapsed time is the kernel's own duration.
 int slam_prof_slot(slam_ctx* ctx, int kernel);  // next free event pair, or -1
 
@@ -108,10 +123,10 @@ static inline int slam_launch(slam_ctx* ctx, int kernel_id, void (*kernel)(KArgs
                               unsigned shmem, Args... args) {
     int slot = (ctx->profiling && kernel_id >= 0) ? slam_prof_slot(ctx, kernel_id) : -1;
     if (slot >= 0)
-        hipExtLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, ctx->prof.start[slot], ctx->prof.stop[slot], 0,
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, ctx->cur, ctx->prof.start[slot], ctx->prof.stop[slot], 0,
                               static_cast<KArgs>(args)...);
     else
-        hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, static_cast<KArgs>(args)...);
+        hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->cur, static_cast<KArgs>(args)...);
     SLAM_HIP(ctx, hipGetLastError());
     return SLAM_OK;
 }

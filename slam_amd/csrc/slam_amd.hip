@@ -52,7 +52,11 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return fail("hipStreamCreate", e);
-    ctx->stream = ctx->own_stream;
+    ctx->stream = ctx->cur = ctx->own_stream;
+    ctx->lane_stream[0] = ctx->own_stream;
+    for (int l = 1; l < SLAM_LANES; ++l)
+        if ((e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking)) != hipSuccess)
+            return fail("hipStreamCreate", e);
     if ((e = hipHostMalloc((void**)&ctx->h_small, 256 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
         return fail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&ctx->h_flags, 16 * sizeof(int32_t), hipHostMallocDefault)) != hipSuccess)
@@ -75,11 +79,17 @@ extern "C" int slam_create(int device, slam_ctx** out) {
 extern "C" void slam_destroy(slam_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)slam_sync_all(ctx);
     slam_buf* bufs[] = {&ctx->pts, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
                         &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags};
     for (slam_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (int l = 0; l < SLAM_LANES; ++l) {
+        if (ctx->lane_F[l].p) (void)hipFree(ctx->lane_F[l].p);
+        if (ctx->lane_counts[l].p) (void)hipFree(ctx->lane_counts[l].p);
+        if (ctx->lane_errsums[l].p) (void)hipFree(ctx->lane_errsums[l].p);
+        if (l > 0 && ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
+    }
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->prof.created)
@@ -95,15 +105,23 @@ extern "C" const char* slam_last_error(const slam_ctx* ctx) { return ctx ? ctx->
 
 extern "C" int slam_set_stream(slam_ctx* ctx, void* hip_stream) {
     if (!ctx) return SLAM_EINVAL;
-    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    SLAM_TRY(slam_sync_all(ctx));
+    ctx->stream = ctx->cur = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SLAM_OK;
+}
+
+extern "C" int slam_set_concurrency(slam_ctx* ctx, int lanes) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, lanes >= 1 && lanes <= SLAM_LANES, "lanes must be 1..3");
+    SLAM_TRY(slam_sync_all(ctx));
+    ctx->lanes_in_use = lanes;
+    ctx->next_lane = 0;
     return SLAM_OK;
 }
 
 extern "C" int slam_synchronize(slam_ctx* ctx) {
     if (!ctx) return SLAM_EINVAL;
-    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return SLAM_OK;
+    return slam_sync_all(ctx);
 }
 
 // ================================================================================================
@@ -112,7 +130,7 @@ extern "C" int slam_synchronize(slam_ctx* ctx) {
 static int prof_flush(slam_ctx* ctx) {
     slam_prof& p = ctx->prof;
     if (p.used == 0) return SLAM_OK;
-    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SLAM_TRY(slam_sync_all(ctx));
     for (int i = 0; i < p.used; ++i) {
         float ms = 0.f;
         SLAM_HIP(ctx, hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
@@ -379,8 +397,23 @@ extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double
                                  int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
                                  uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all) {
     if (!ctx) return SLAM_EINVAL;
-    return ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
-                          d_errsums, d_F_all);
+    SLAM_REQUIRE(ctx, H >= 1, "H < 1");
+    // With slam_set_concurrency(n > 1) independent calls rotate over the context's internal streams (each with its
+    // own hypothesis scratch) so that one call's selection kernel and the next call's solve phase overlap.  With a
+    // caller-supplied stream, or n = 1 (the default), every call stays on one stream, in order.
+    int lane = 0;
+    if (ctx->stream == ctx->own_stream && ctx->lanes_in_use > 1) lane = (int)(ctx->next_lane++ % (unsigned)ctx->lanes_in_use);
+    if (lane > 0) {
+        if (sampler == SLAM_SAMPLER_CPYTHON && !d_idx) SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));  // on the ordered stream
+        if (!d_F_all) { SLAM_TRY(slam_reserve(ctx, ctx->lane_F[lane], (size_t)H * 9 * sizeof(double))); d_F_all = (double*)ctx->lane_F[lane].p; }
+        if (!d_counts) { SLAM_TRY(slam_reserve(ctx, ctx->lane_counts[lane], (size_t)H * sizeof(int32_t))); d_counts = (int32_t*)ctx->lane_counts[lane].p; }
+        if (!d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->lane_errsums[lane], (size_t)H * sizeof(double))); d_errsums = (double*)ctx->lane_errsums[lane].p; }
+    }
+    ctx->cur = ctx->lane_stream[lane] && ctx->stream == ctx->own_stream ? ctx->lane_stream[lane] : ctx->stream;
+    const int rc = ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
+                                  d_errsums, d_F_all);
+    ctx->cur = ctx->stream;
+    return rc;
 }
 
 // stage two (N,2) point arrays contiguously in ctx->pts; returns device pointers

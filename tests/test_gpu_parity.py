@@ -334,3 +334,45 @@ def test_whole_pair_matches_reference(ctx, name):
     pose, X = epipolar.calculate_pose_from_essential_matrix(E, g["pts0"], g["pts1"], g["K"])
     assert np.allclose(pose, r["pose"], atol=1e-9)
     assert point_err(X, r["X"]) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------- device-resident API
+def test_device_calls_in_flight_match_serial(ctx):
+    """slam_ransac_f_dev on device-resident matches: with three calls in flight on the context's internal streams
+    every call returns bit for bit what it returns alone."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    jobs = []
+    for j, (n, h) in enumerate([(4096, 2048), (1000, 777), (3000, 1500), (256, 300), (4096, 2048), (5000, 4096), (100, 1000)]):
+        d = synth.make_pair(n, 0.3, seed=200 + j)
+        n0, _ = so.normalize_points(d["pts0"])
+        n1, _ = so.normalize_points(d["pts1"])
+        jobs.append((n, h, torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)))
+    torch.cuda.synchronize()
+
+    def run(lanes):
+        ctx.check(lib.slam_set_concurrency(ctx.handle, lanes))
+        recs = [torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev) for _ in jobs]
+        masks = [torch.zeros(n, dtype=torch.uint8, device=dev) for n, _, _, _ in jobs]
+        for rep in range(3):
+            for (n, h, p0, p1), r, m in zip(jobs, recs, masks):
+                ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), n, None, _lib.SAMPLER_CPYTHON,
+                                                _lib.SEED_BASE, 0, h, 0.005, r.data_ptr(), m.data_ptr(), None, None, None))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        return [r.cpu().numpy() for r in recs], [m.cpu().numpy() for m in masks]
+
+    try:
+        serial = run(1)
+        overlapped = run(3)
+    finally:
+        ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
+    for a, b in zip(serial[0], overlapped[0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(serial[1], overlapped[1]):
+        assert np.array_equal(a, b)
+    # and the device-resident result is the host entry point's result
+    n, h, p0, p1 = jobs[2]
+    host = epipolar.ransac_detailed(p0.cpu().numpy(), p1.cpu().numpy(), h)
+    assert np.array_equal(host["record"], serial[0][2])
+    assert np.array_equal(host["best_mask"], serial[1][2].astype(bool))

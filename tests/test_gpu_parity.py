@@ -376,3 +376,127 @@ def test_device_calls_in_flight_match_serial(ctx):
     host = epipolar.ransac_detailed(p0.cpu().numpy(), p1.cpu().numpy(), h)
     assert np.array_equal(host["record"], serial[0][2])
     assert np.array_equal(host["best_mask"], serial[1][2].astype(bool))
+
+
+# ---------------------------------------------------------------------------------------------- full benchmark sizes
+def test_config3_full_size_properties(ctx):
+    """N=65536 matches, 70% outliers, 2^20 hypotheses (configuration 3) at full size: the unsharded run equals the
+    merge of eight contiguous ranges bit for bit, and a sample of hypotheses is checked against the C restatement."""
+    import torch
+    N, H = 65536, 1 << 20
+    d = synth.make_pair(N, 0.7, seed=3)
+    n0, _ = so.normalize_points(d["pts0"])
+    n1, _ = so.normalize_points(d["pts1"])
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    p0, p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+    counts = torch.zeros(H, dtype=torch.int32, device=dev)
+    errs = torch.zeros(H, dtype=torch.float64, device=dev)
+    rec = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    mask = torch.zeros(N, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 3, 0, H, 0.005,
+                                    rec.data_ptr(), mask.data_ptr(), counts.data_ptr(), errs.data_ptr(), None))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    full_rec, full_counts, full_errs = rec.cpu().numpy().copy(), counts.cpu().numpy().copy(), errs.cpu().numpy().copy()
+    parts = []
+    c2 = torch.zeros(H, dtype=torch.int32, device=dev)
+    e2 = torch.zeros(H, dtype=torch.float64, device=dev)
+    for g in range(8):
+        lo, hi = pipeline.shard_range(H, g, 8)
+        r = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+        ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 3, lo, hi - lo,
+                                        0.005, r.data_ptr(), None, c2[lo:].data_ptr(), e2[lo:].data_ptr(), None))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        parts.append(r.cpu().numpy())
+    assert np.array_equal(c2.cpu().numpy(), full_counts)
+    assert np.array_equal(e2.cpu().numpy(), full_errs)
+    _, win = pipeline.merge_records(parts)
+    assert np.array_equal(win, full_rec)
+    assert int(mask.sum().item()) == int(full_rec[_lib.REC_COUNT]) == int(full_counts.max())
+    # a random sample of hypotheses (and the winner) against the C restatement on the same index sets
+    pick = np.unique(np.concatenate([np.random.default_rng(1).integers(0, H, 96), [int(full_rec[_lib.REC_INDEX])]]))
+    idx = so.sample_indices_counter(N, pick, seed=3)
+    o = co.ransac(n0, n1, idx, threads=8, want_mask=False)
+    assert np.array_equal(o["counts"], full_counts[pick])
+    assert np.allclose(o["errsums"], full_errs[pick], rtol=1e-9)
+    w = int(np.flatnonzero(pick == int(full_rec[_lib.REC_INDEX]))[0])
+    assert rel_err(fix_sign_scale(o["F"][w]), fix_sign_scale(full_rec[_lib.REC_F:].reshape(3, 3))) < F_TOL
+
+
+def test_config5_full_size_properties(ctx):
+    """16 777 216 correspondences, four candidates (configuration 5) at full size: the cheirality counts of the whole
+    set equal the sum over four point shards (what ranks all-reduce), the winner's points equal the shards'
+    points, and a random sample of points is checked against the C restatement."""
+    import torch
+    NT = 1 << 24
+    base = synth.make_pair(1 << 18, 0.2, seed=5)
+    rng = np.random.default_rng(55)
+    reps = NT // (1 << 18)
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    p0 = torch.from_numpy(base["pts0"]).to(dev).repeat(reps, 1).contiguous()
+    p1 = torch.from_numpy(base["pts1"]).to(dev).repeat(reps, 1).contiguous()
+    torch.manual_seed(55)
+    p1 += (torch.rand_like(p1) - 0.5)              # every correspondence distinct
+    E = np.ascontiguousarray(synth.essential_from_motion(base["R"], base["t"]))
+    K = np.ascontiguousarray(base["K"])
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    pose = torch.zeros(16, dtype=torch.float64, device=dev)
+    X = torch.empty((NT, 3), dtype=torch.float64, device=dev)
+    win = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0.data_ptr(), p1.data_ptr(), NT, counts.data_ptr()))
+    ctx.check(lib.slam_pose_select_dev(ctx.handle, counts.data_ptr(), NT, pose.data_ptr(), X.data_ptr(), win.data_ptr()))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    full_counts = counts.cpu().numpy().copy()
+    w = int(win.item())
+    assert full_counts[w] == full_counts.max() and 0 < full_counts.sum()
+    # point shards: counts add up; with the summed counts every shard picks the same winner and returns its slice
+    total = np.zeros(4, dtype=np.int64)
+    shard_counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    Q = NT // 4
+    for s in range(4):
+        ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0[s * Q:].data_ptr(), p1[s * Q:].data_ptr(),
+                                               Q, shard_counts.data_ptr()))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        total += shard_counts.cpu().numpy()
+    assert np.array_equal(total, full_counts)
+    summed = torch.from_numpy(total).to(dev)
+    Xs = torch.empty((Q, 3), dtype=torch.float64, device=dev)
+    ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0[3 * Q:].data_ptr(), p1[3 * Q:].data_ptr(), Q,
+                                           shard_counts.data_ptr()))
+    ctx.check(lib.slam_pose_select_dev(ctx.handle, summed.data_ptr(), Q, pose.data_ptr(), Xs.data_ptr(), win.data_ptr()))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    assert int(win.item()) == w
+    assert torch.equal(Xs, X[3 * Q:])
+    # sample of points against the C restatement
+    pick = np.sort(rng.choice(NT, 50000, replace=False))
+    tp = torch.from_numpy(pick).to(dev)
+    s0, s1 = p0[tp].cpu().numpy(), p1[tp].cpu().numpy()
+    ref_pose, ref_X, ref_counts, ref_w = co.pose_from_E(E, K, s0, s1, threads=8)
+    assert np.allclose(pose.cpu().numpy().reshape(4, 4), ref_pose, atol=1e-9)
+    got = X[tp].cpu().numpy()
+    rel = np.abs(got - ref_X) / np.maximum(np.abs(ref_X), 1e-3 * np.abs(ref_X).max(axis=1, keepdims=True))
+    assert np.quantile(rel, 0.999) < 1e-8 and rel.max() < X_TOL
+
+
+def test_config4_batch_of_pairs(ctx):
+    """Configuration 4 shape: independent frame pairs (N=2048, 1000 iterations, seeds 100+pair) through the whole-pair
+    entry point, each checked against the C restatement step by step."""
+    for pair in range(12):
+        d = synth.make_pair(2048, 0.3, seed=100 + pair)
+        r = pipeline.initialise_pair(d["pts0"], d["pts1"], d["K"], iterations=1000)
+        n0, T0 = co.normalize_points(d["pts0"])
+        n1, T1 = co.normalize_points(d["pts1"])
+        o = co.ransac(n0, n1, co.sample(2048, 1000), threads=8)
+        assert int(r["record"][_lib.REC_INDEX]) == o["best_index"], pair
+        assert int(r["record"][_lib.REC_COUNT]) == o["best_count"]
+        F = T1.T @ o["best_F"] @ T0
+        assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(F)) < F_TOL
+        E = so.fundamental_to_essential(F, d["K"])
+        pose, X, counts, w = co.pose_from_E(E, d["K"], d["pts0"], d["pts1"], threads=8)
+        assert sorted(r["counts"].tolist()) == sorted(counts.tolist())
+        assert np.allclose(r["pose"], pose, atol=1e-7)
+        assert point_err(r["X"], X) < X_TOL
+        assert np.array_equal(r["mask"], X[:, 2] > 0)

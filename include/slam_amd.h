@@ -131,12 +131,42 @@ int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* pts1, int N,
                    double* F, double* E, double* pose, double* X, uint8_t* good, double* record,
                    int32_t* counts4, int32_t* winner);
 
+/* ---- tracking step: src/triangulation.py:78-182 ------------------------------------------------- */
+/* number of hypotheses the tracking loop runs: min(iterations, C(M, 6))   (src/triangulation.py:145-146) */
+int64_t slam_num_tracking_hypotheses(int64_t n_known, int64_t iterations);
+/* src/triangulation.py:78-132 triangulate_pose_from_points: camera pose from M >= 6 matches between image points
+ * (M,2) and known 3D points (M,3) by DLT resection.  pose: 4x4.  extra (may be NULL): 24 values, the quantities the
+ * reference prints: calculated intrinsic matrix (9), rotation (9), translation (3), camera centre (3).
+ * The intrinsic matrix argument of the reference is not used by it and has no counterpart here. */
+int slam_pose_from_points(slam_ctx* ctx, const double* image_points, const double* known_3d_points, int M,
+                          double* pose, double* extra);
+/* src/triangulation.py:135-182 triangulate_pose_from_points_with_ransac.
+ * previous_pose: 4x4 (host).  prev_known/next_known (M,2), known_3d_points (M,3): the matches with a known 3D
+ * position; prev_all/next_all (N,2): every match, triangulated at the end with (previous_pose, winning pose) as the
+ * reference does (4x4 poses, no K).  Draws min(iterations, C(M,6)) samples of 6 with the reference's seeds
+ * (src/triangulation.py:154-155), solves, scores each by points in front of both cameras and then by the summed 3D
+ * distance to the known points, and keeps the first best.
+ * Outputs: pose (16); X (N,3) (may be NULL when N == 0); best[3] = winner position, its count, its error (may be
+ * NULL); counts[H], errs[H], poses[H*16] per hypothesis (each may be NULL). */
+int slam_track_pose(slam_ctx* ctx, const double* previous_pose, const double* prev_known, const double* next_known,
+                    const double* known_3d_points, int M, const double* prev_all, const double* next_all, int64_t N,
+                    const double* K, int iterations, double* pose, double* X, double* best, int32_t* counts,
+                    double* errs, double* poses);
+/* same with device pointers for the point arrays and outputs (previous_pose and K stay host pointers, they travel
+ * as kernel arguments); asynchronous on the context's stream.  d_best: 3 doubles. */
+int slam_track_pose_dev(slam_ctx* ctx, const double* previous_pose, const double* d_prev_known,
+                        const double* d_next_known, const double* d_known_3d_points, int M, const double* d_prev_all,
+                        const double* d_next_all, int64_t N, const double* K, int iterations, double* d_pose,
+                        double* d_X, double* d_best);
+
 /* ---- kernel timing for benchmarks ---------------------------------------------------------------- */
 #define SLAM_K_SOLVE 0
 #define SLAM_K_SCORE 1
 #define SLAM_K_SELECT 2
 #define SLAM_K_TRIANGULATE 3
-#define SLAM_K_COUNT 4
+#define SLAM_K_RESECT 4
+#define SLAM_K_TRACK_SCORE 5
+#define SLAM_K_COUNT 6
 /* When enabled, every launch of the kernels above is bracketed by HIP events on the context's stream. */
 int slam_profile_enable(slam_ctx* ctx, int on);
 /* Synchronises, then returns total milliseconds and number of launches recorded for `kernel` since the last reset. */

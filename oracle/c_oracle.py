@@ -38,6 +38,9 @@ def lib():
         L.oracle_pose_candidates.argtypes = [_f64, _f64, _f64]
         L.oracle_pose_from_E.argtypes = [_f64, _f64, _f64, _f64, C.c_int64, _f64, _f64, _i32,
                                          C.POINTER(C.c_int32), C.c_int]
+        L.oracle_pose_from_points.argtypes = [_f64, _f64, C.c_int, _f64, C.c_void_p]
+        L.oracle_tracking_ransac.argtypes = [_f64, _f64, _f64, _f64, C.c_int, _f64, _i32, C.c_int, _f64, _i32, _f64,
+                                             C.POINTER(C.c_int32)]
         _LIB = L
     return _LIB
 
@@ -113,3 +116,26 @@ def pose_from_E(E, K, p0, p1, threads=1):
     w = C.c_int32(-1)
     lib().oracle_pose_from_E(_c(E), _c(K), p0, p1, len(p0), pose, X, counts, C.byref(w), threads)
     return pose, X, counts, int(w.value)
+
+
+def pose_from_points(image_points, known_3d_points, want_extra=False):
+    uv, X = _c(image_points), _c(known_3d_points)
+    pose = np.empty((4, 4))
+    extra = np.empty(24)
+    assert lib().oracle_pose_from_points(uv, X, len(uv), pose, extra.ctypes.data) == 0
+    if want_extra:
+        return pose, dict(K=extra[:9].reshape(3, 3), R=extra[9:18].reshape(3, 3), t=extra[18:21], centre=extra[21:24])
+    return pose
+
+
+def tracking_ransac(previous_pose, prev_known, next_known, known_3d_points, K, idx):
+    a, b, X3, idx = _c(prev_known), _c(next_known), _c(known_3d_points), _c(idx, np.int32)
+    H = len(idx)
+    poses = np.empty((H, 4, 4))
+    counts = np.empty(H, dtype=np.int32)
+    errs = np.empty(H)
+    bi = C.c_int32(-1)
+    rc = lib().oracle_tracking_ransac(_c(previous_pose), a, b, X3, len(a), _c(K), idx, H, poses, counts, errs,
+                                      C.byref(bi))
+    assert rc == 0
+    return dict(poses=poses, counts=counts, errs=errs, best_index=int(bi.value), pose=poses[bi.value])

@@ -439,3 +439,132 @@ int oracle_pose_from_E(const double* E, const double* K, const double* p0, const
     free(Xc);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * tracking step: camera pose from 2D-3D matches and its RANSAC loop
+ * src/triangulation.py:78-182, src/util.py:18-27,60-66
+ * ---------------------------------------------------------------------------------- */
+/* uv: M x 2 image points, X: M x 3 known points.  pose: 4x4.  extra (may be NULL): 9 (calculated K) + 9 (rotation)
+ * + 3 (translation) + 3 (camera centre), the quantities the reference prints. */
+int oracle_pose_from_points(const double* uv, const double* X, int M, double* pose, double* extra) {
+    if (M < 6) return -1;                                                                                /* :82 */
+    const int rows = 2 * M;
+    double* A = (double*)calloc((size_t)rows * 12, sizeof(double));
+    double V[144], n2[12];
+    for (int i = 0; i < M; i++) {                                                                        /* :98-100 */
+        const double u = uv[2 * i], v = uv[2 * i + 1];
+        const double xh[4] = { X[3 * i], X[3 * i + 1], X[3 * i + 2], 1.0 };
+        double* e = A + (size_t)(2 * i) * 12;
+        double* o = e + 12;
+        for (int j = 0; j < 4; j++) {
+            e[4 + j] = -xh[j]; e[8 + j] = v * xh[j];
+            o[j] = xh[j];      o[8 + j] = -u * xh[j];
+        }
+    }
+    jacobi_svd(A, rows, 12, V);                                                                          /* :112 */
+    column_norms2(A, rows, 12, n2);
+    free(A);
+    int least = 0;
+    for (int j = 1; j < 12; j++) if (n2[j] < n2[least]) least = j;
+    double cam[12];
+    for (int i = 0; i < 12; i++) cam[i] = V[i * 12 + least];                                             /* :113-114 */
+    const double m3[9] = { cam[0], cam[1], cam[2], cam[4], cam[5], cam[6], cam[8], cam[9], cam[10] };
+    const double d = det3(m3);
+    const double sg = d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0);                                                /* :115 */
+    for (int i = 0; i < 12; i++) cam[i] *= sg;
+    /* :117-118  the null vector of the 3x4 matrix, by cofactors; only its ratios are used */
+    double c4[4];
+    for (int k = 0; k < 4; k++) {
+        double s[9];
+        int cc = 0;
+        for (int j = 0; j < 4; j++) {
+            if (j == k) continue;
+            s[cc] = cam[j]; s[3 + cc] = cam[4 + j]; s[6 + cc] = cam[8 + j];
+            cc++;
+        }
+        c4[k] = ((k & 1) ? -1.0 : 1.0) * det3(s);
+    }
+    const double centre[3] = { c4[0] / c4[3], c4[1] / c4[3], c4[2] / c4[3] };
+    /* :120  rq_decomposition(m) of src/util.py:60-66: J m = q' r' (Gram-Schmidt here; the signs LAPACK would pick
+       cancel in :122-124), r = J r'^T J, q = J q'^T */
+    double Mp[9], Q[9], Rp[9] = { 0 };
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Mp[3 * i + j] = sg * m3[3 * (2 - i) + j];
+    for (int j = 0; j < 3; j++) {
+        double v[3] = { Mp[j], Mp[3 + j], Mp[6 + j] };
+        for (int pass = 0; pass < 2; pass++)                         /* twice: re-orthogonalisation */
+            for (int k = 0; k < j; k++) {
+                double dot = 0;
+                for (int i = 0; i < 3; i++) dot += Q[3 * i + k] * v[i];
+                Rp[3 * k + j] += dot;
+                for (int i = 0; i < 3; i++) v[i] -= dot * Q[3 * i + k];
+            }
+        const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        Rp[3 * j + j] = nrm;
+        for (int i = 0; i < 3; i++) Q[3 * i + j] = v[i] / nrm;
+    }
+    double r[9], q[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        r[3 * i + j] = Rp[3 * (2 - j) + (2 - i)];                     /* (J r'^T J)_ij = r'_(2-j)(2-i) */
+        q[3 * i + j] = Q[3 * j + (2 - i)];                            /* (J q'^T)_ij = q'_j(2-i) */
+    }
+    double dg[3], Kc[9], R[9], t[3];
+    for (int i = 0; i < 3; i++) dg[i] = r[4 * i] > 0 ? 1.0 : (r[4 * i] < 0 ? -1.0 : 0.0);                /* :122 */
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Kc[3 * i + j] = r[3 * i + j] * dg[j]; R[3 * i + j] = dg[i] * q[3 * i + j]; }
+    for (int i = 0; i < 3; i++) t[i] = -1 * (R[3 * i] * centre[0] + R[3 * i + 1] * centre[1] + R[3 * i + 2] * centre[2]);   /* :125 */
+    rt_to_pose(R, t, pose);                                                                              /* :132 */
+    if (extra) { memcpy(extra, Kc, sizeof Kc); memcpy(extra + 9, R, sizeof R); memcpy(extra + 18, t, sizeof t); memcpy(extra + 21, centre, sizeof centre); }
+    return 0;
+}
+
+static void mat34_from_K_pose(const double* K, const double* pose, double* P) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += K[3 * i + k] * pose[4 * k + j];
+        P[4 * i + j] = s;
+    }
+}
+
+/* idx: H x 6 sample indices.  a, b: M x 2 previous/next image points of the matches with known 3D position X3 (M x 3).
+ * Outputs: poses (H x 16), counts (H), errs (H), best (winner position), any of the first three may be NULL. */
+int oracle_tracking_ransac(const double* prev_pose, const double* a, const double* b, const double* X3, int M,
+                           const double* K, const int32_t* idx, int H, double* poses, int32_t* counts, double* errs,
+                           int32_t* best) {
+    if (M < 6 || H < 1) return -1;
+    double P0[12], P1[12], pose[16];
+    double* Xt = (double*)malloc(sizeof(double) * 3 * (size_t)M);
+    mat34_from_K_pose(K, prev_pose, P0);
+    int32_t bc = -1, bi = -1;
+    double be = 0;
+    for (int h = 0; h < H; h++) {
+        double uv[12], xs[18];
+        for (int j = 0; j < 6; j++) {
+            const int32_t i = idx[6 * h + j];
+            uv[2 * j] = b[2 * i]; uv[2 * j + 1] = b[2 * i + 1];
+            xs[3 * j] = X3[3 * i]; xs[3 * j + 1] = X3[3 * i + 1]; xs[3 * j + 2] = X3[3 * i + 2];
+        }
+        oracle_pose_from_points(uv, xs, 6, pose, NULL);                                                  /* :156-158 */
+        mat34_from_K_pose(K, pose, P1);
+        oracle_triangulate(P0, P1, a, b, M, Xt, 1);                                                      /* :159-162 */
+        /* rotation = pose[:3,:3]^T, translation = -pose[:3,:3]^T pose[:3,3]   (src/util.py:18-27) */
+        const double cz[3] = { pose[8], pose[9], pose[10] };                                             /* R (0,0,1)^T  :166 */
+        double t[3];
+        for (int i = 0; i < 3; i++) t[i] = -1 * (pose[i] * pose[3] + pose[4 + i] * pose[7] + pose[8 + i] * pose[11]);
+        int32_t c = 0;
+        double e = 0;
+        for (int i = 0; i < M; i++) {
+            const double* x = Xt + 3 * i;
+            const int f1 = x[2] > 0;                                                                     /* :167 */
+            const int f2 = ((x[0] - t[0]) * cz[0] + (x[1] - t[1]) * cz[1] + (x[2] - t[2]) * cz[2]) > 0;  /* :168 */
+            c += f1 && f2;
+            const double dx = X3[3 * i] - x[0], dy = X3[3 * i + 1] - x[1], dz = X3[3 * i + 2] - x[2];
+            e += sqrt(dx * dx + dy * dy + dz * dz);                                                      /* :170 */
+        }
+        if (poses) memcpy(poses + 16 * (size_t)h, pose, sizeof pose);
+        if (counts) counts[h] = c;
+        if (errs) errs[h] = e;
+        if (c > bc || (c == bc && be > e)) { bc = c; be = e; bi = h; }                                   /* :172-173 */
+    }
+    free(Xt);
+    *best = bi;
+    return 0;
+}

@@ -5,7 +5,9 @@ There is no fallback: if the shared library is missing or no gfx950 GPU is usabl
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -17,7 +19,7 @@ REC_COUNT, REC_ERRSUM, REC_INDEX, REC_F, REC_LEN = 0, 1, 2, 3, 12
 SAMPLER_CPYTHON, SAMPLER_COUNTER = 0, 1
 SEED_BASE = 0x1337BEEF
 DEFAULT_THRESHOLD = 0.005
-K_SOLVE, K_SCORE, K_SELECT, K_TRIANGULATE = 0, 1, 2, 3
+K_SOLVE, K_SCORE, K_SELECT, K_TRIANGULATE, K_RESECT, K_TRACK_SCORE = 0, 1, 2, 3, 4, 5
 
 # every symbol include/slam_amd.h declares, with its ctypes signature
 _vp, _i32, _i64, _u64, _f64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_int
@@ -42,6 +44,10 @@ SIGNATURES = {
     "slam_pose_candidates_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "slam_pose_select_dev": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "slam_init_pair": (_int, [_vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slam_num_tracking_hypotheses": (_i64, [_i64, _i64]),
+    "slam_pose_from_points": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
+    "slam_track_pose": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slam_track_pose_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "slam_profile_enable": (_int, [_vp, _int]),
     "slam_profile_read": (_int, [_vp, _int, C.POINTER(_f64), C.POINTER(_i64)]),
     "slam_profile_reset": (_int, [_vp]),
@@ -56,6 +62,28 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own copy of the HIP and HSA runtimes.  Two copies in one process do not both
+    get the GPU: the one that initialises second sees no device.  When torch is installed but not imported yet, load
+    its copy first, so that libslam_amd binds to it and a later `import torch` finds it already in the process
+    (the order torch-then-libslam_amd needs nothing: the library then binds to torch's copy by itself).
+    SLAM_AMD_SYSTEM_HIP=1 keeps the system runtime."""
+    if "torch" in sys.modules or os.environ.get("SLAM_AMD_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the library and declare the signatures (does not touch the GPU)."""
     global _lib
@@ -64,6 +92,7 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise SlamError(f"{LIB_PATH} is missing: build it with `make -C slam_amd/csrc` "
                                 "(there is no CPU fallback)")
+            _share_hip_runtime_with_torch()
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

@@ -22,8 +22,8 @@ struct slam_prof {
     int kernel[kMax];
     int used = 0;
     bool created = false;
-    double total_ms[SLAM_K_COUNT] = {0, 0, 0, 0};
-    int64_t launches[SLAM_K_COUNT] = {0, 0, 0, 0};
+    double total_ms[SLAM_K_COUNT] = {};
+    int64_t launches[SLAM_K_COUNT] = {};
 };
 
 #define SLAM_LANES 3  // internal streams that independent RANSAC calls rotate over
@@ -52,6 +52,7 @@ struct slam_ctx {
     slam_buf X;         // N*3 f64 staging
     slam_buf small;     // small matrices: candidates, poses, T, E ...
     slam_buf flags;     // int32[4] error flags written by kernels
+    slam_buf track;     // tracking step: work block + per-hypothesis blocks
     uint64_t raw_seed = 0;
     int64_t raw_it0 = 0, raw_n = 0;
 

@@ -10,6 +10,7 @@
 #include "ctx.h"
 #include "kernels_ransac.h"
 #include "kernels_tri.h"
+#include "kernels_track.h"
 
 using namespace slamk;
 
@@ -81,7 +82,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)slam_sync_all(ctx);
     slam_buf* bufs[] = {&ctx->pts, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
-                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags};
+                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track};
     for (slam_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int l = 0; l < SLAM_LANES; ++l) {
@@ -704,6 +705,149 @@ extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* p
     const int64_t* c = (const int64_t*)(hs + 32);
     if (counts4) for (int i = 0; i < 4; ++i) counts4[i] = (int32_t)c[i];
     if (winner) *winner = *(const int32_t*)(hs + 60);
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// tracking step
+// ================================================================================================
+static int64_t num_subsets_capped(int64_t n, int k, int64_t cap) {
+    if (n < k || cap < 0) return 0;
+    unsigned __int128 c = 1;
+    for (int i = 1; i <= k; ++i) {
+        c = c * (unsigned __int128)(n - k + i) / (unsigned)i;  // exact: C(n-k+i, i) after each step, growing with i
+        if (c > (unsigned __int128)cap) return cap;
+    }
+    return (int64_t)c;
+}
+
+extern "C" int64_t slam_num_tracking_hypotheses(int64_t n_known, int64_t iterations) {
+    return num_subsets_capped(n_known, 6, iterations);
+}
+
+extern "C" int slam_pose_from_points(slam_ctx* ctx, const double* image_points, const double* known_3d_points, int M,
+                                     double* pose, double* extra) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, image_points && known_3d_points && pose, "NULL pointer");
+    SLAM_REQUIRE(ctx, M >= 6, "fewer than 6 matches");  // reference: src/triangulation.py:82
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t b2 = (size_t)M * 2 * sizeof(double), b3 = (size_t)M * 3 * sizeof(double);
+    SLAM_TRY(slam_reserve(ctx, ctx->pts, b2 + b3 + 64));
+    SLAM_TRY(slam_reserve(ctx, ctx->track, (size_t)(TW_LEN + HP_LEN) * sizeof(double)));
+    double* duv = (double*)ctx->pts.p;
+    double* dX = (double*)((char*)ctx->pts.p + ((b2 + 63) & ~(size_t)63));
+    double* tw = (double*)ctx->track.p;
+    double* hyp = tw + TW_LEN;
+    SLAM_HIP(ctx, hipMemcpyAsync(duv, image_points, b2, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(dX, known_3d_points, b3, hipMemcpyHostToDevice, ctx->stream));
+    TrackSetup ts;
+    memset(&ts, 0, sizeof ts);
+    ts.K[0] = ts.K[4] = ts.K[8] = 1.0;
+    SLAM_TRY(slam_launch(ctx, -1, k_track_setup, dim3(1), dim3(64), 0, ts, tw));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect, dim3(1), dim3(SLAM_RESECT_LANES), 0, (const double2*)duv,
+                         (const double*)dX, M, (const int32_t*)nullptr, 1, (const double*)tw, hyp));
+    SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_small, hyp, HP_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(pose, ctx->h_small + HP_POSE, 16 * sizeof(double));
+    if (extra) memcpy(extra, ctx->h_small + HP_EXTRA, 24 * sizeof(double));
+    return SLAM_OK;
+}
+
+// queues sample -> resect -> score -> select -> final triangulation; everything stays on the device
+static int track_enqueue(slam_ctx* ctx, const double* previous_pose, const double* d_a, const double* d_b,
+                         const double* d_X3, int M, const double* d_prev_all, const double* d_next_all, int64_t N,
+                         const double* K, int H, double* d_pose, double* d_X) {
+    SLAM_TRY(slam_fill_raw_table(ctx, SLAM_SEED_BASE, 0, H));
+    SLAM_TRY(slam_reserve(ctx, ctx->idx, (size_t)H * 8 * sizeof(int32_t)));
+    SLAM_TRY(slam_reserve(ctx, ctx->track, ((size_t)TW_LEN + (size_t)H * HP_LEN) * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t)));
+    SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
+    double* tw = (double*)ctx->track.p;
+    double* hyp = tw + TW_LEN;
+    TrackSetup ts;
+    memcpy(ts.K, K, sizeof ts.K);
+    memcpy(ts.prev, previous_pose, sizeof ts.prev);  // the first three rows of the 4x4 pose
+    SLAM_TRY(slam_launch(ctx, -1, k_track_setup, dim3(1), dim3(64), 0, ts, tw));
+    SLAM_TRY(slam_launch(ctx, -1, k_sample, dim3((H + 63) / 64), dim3(64), 0, (int)SLAM_SAMPLER_CPYTHON,
+                         (uint64_t)SLAM_SEED_BASE, (int64_t)0, H, M, 6, (const uint32_t*)ctx->raw.p, ctx->raw_it0,
+                         (int32_t*)ctx->idx.p, (int32_t*)ctx->flags.p));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect, dim3((H + SLAM_RESECT_LANES - 1) / SLAM_RESECT_LANES),
+                         dim3(SLAM_RESECT_LANES), 0, (const double2*)d_b, d_X3, M, (const int32_t*)ctx->idx.p, H,
+                         (const double*)tw, hyp));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_TRACK_SCORE, k_track_score, dim3(H), dim3(256), 0, (const double*)tw,
+                         (const double*)hyp, (const double2*)d_a, (const double2*)d_b, d_X3, M,
+                         (int32_t*)ctx->counts.p, (double*)ctx->errsums.p));
+    SLAM_TRY(slam_launch(ctx, -1, k_track_select, dim3(1), dim3(64), 0, (const int32_t*)ctx->counts.p,
+                         (const double*)ctx->errsums.p, H, (const double*)hyp, tw, d_pose));
+    if (N > 0)
+        SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate_cams, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                             (const double*)(tw + TW_WIN), (const double2*)d_prev_all, (const double2*)d_next_all, N, d_X));
+    return SLAM_OK;
+}
+
+#define SLAM_TRACK_ARGS_OK(ctx, M, N, iterations)                                           \
+    SLAM_REQUIRE(ctx, (M) >= 6, "fewer than 6 matches with a known 3D position");           \
+    SLAM_REQUIRE(ctx, (N) >= 0 && (N) < ((int64_t)1 << 31) * 256, "N out of range");        \
+    SLAM_REQUIRE(ctx, (iterations) >= 1, "iterations < 1")
+
+extern "C" int slam_track_pose_dev(slam_ctx* ctx, const double* previous_pose, const double* d_prev_known,
+                                   const double* d_next_known, const double* d_known_3d_points, int M,
+                                   const double* d_prev_all, const double* d_next_all, int64_t N, const double* K,
+                                   int iterations, double* d_pose, double* d_X, double* d_best) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, previous_pose && d_prev_known && d_next_known && d_known_3d_points && K && d_pose, "NULL pointer");
+    SLAM_TRACK_ARGS_OK(ctx, M, N, iterations);
+    SLAM_REQUIRE(ctx, N == 0 || (d_prev_all && d_next_all && d_X), "NULL pointer for the full match list");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int H = (int)slam_num_tracking_hypotheses(M, iterations);
+    SLAM_TRY(track_enqueue(ctx, previous_pose, d_prev_known, d_next_known, d_known_3d_points, M, d_prev_all, d_next_all,
+                           N, K, H, d_pose, d_X));
+    if (d_best)
+        SLAM_HIP(ctx, hipMemcpyAsync(d_best, (double*)ctx->track.p + TW_BEST, 3 * sizeof(double), hipMemcpyDeviceToDevice,
+                                     ctx->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_track_pose(slam_ctx* ctx, const double* previous_pose, const double* prev_known,
+                               const double* next_known, const double* known_3d_points, int M, const double* prev_all,
+                               const double* next_all, int64_t N, const double* K, int iterations, double* pose,
+                               double* X, double* best, int32_t* counts, double* errs, double* poses) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, previous_pose && prev_known && next_known && known_3d_points && K && pose, "NULL pointer");
+    SLAM_TRACK_ARGS_OK(ctx, M, N, iterations);
+    SLAM_REQUIRE(ctx, N == 0 || (prev_all && next_all && X), "NULL pointer for the full match list");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int H = (int)slam_num_tracking_hypotheses(M, iterations);
+    // pts: prev_known | next_known | X_known | prev_all | next_all, each 64-byte aligned
+    const size_t b2 = ((size_t)M * 2 * sizeof(double) + 63) & ~(size_t)63, b3 = ((size_t)M * 3 * sizeof(double) + 63) & ~(size_t)63;
+    const size_t bn = ((size_t)N * 2 * sizeof(double) + 63) & ~(size_t)63;
+    SLAM_TRY(slam_reserve(ctx, ctx->pts, 2 * b2 + b3 + 2 * bn + 64));
+    SLAM_TRY(slam_reserve(ctx, ctx->X, (size_t)(N > 0 ? N : 1) * 3 * sizeof(double)));
+    char* base = (char*)ctx->pts.p;
+    double *da = (double*)base, *db = (double*)(base + b2), *dX3 = (double*)(base + 2 * b2);
+    double *dpa = (double*)(base + 2 * b2 + b3), *dna = (double*)(base + 2 * b2 + b3 + bn);
+    SLAM_HIP(ctx, hipMemcpyAsync(da, prev_known, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(db, next_known, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(dX3, known_3d_points, (size_t)M * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (N > 0) {
+        SLAM_HIP(ctx, hipMemcpyAsync(dpa, prev_all, (size_t)N * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(dna, next_all, (size_t)N * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    double* d_pose = (double*)ctx->small.p + 710;
+    SLAM_TRY(track_enqueue(ctx, previous_pose, da, db, dX3, M, dpa, dna, N, K, H, d_pose, (double*)ctx->X.p));
+    double* tw = (double*)ctx->track.p;
+    double* hs = ctx->h_small;
+    SLAM_HIP(ctx, hipMemcpyAsync(hs, d_pose, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(hs + 16, tw + TW_BEST, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (N > 0) SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (counts) SLAM_HIP(ctx, hipMemcpyAsync(counts, ctx->counts.p, (size_t)H * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (errs) SLAM_HIP(ctx, hipMemcpyAsync(errs, ctx->errsums.p, (size_t)H * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (poses)
+        SLAM_HIP(ctx, hipMemcpy2DAsync(poses, 16 * sizeof(double), tw + TW_LEN + HP_POSE, HP_LEN * sizeof(double),
+                                       16 * sizeof(double), (size_t)H, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_TRY(check_flags(ctx));
+    memcpy(pose, hs, 16 * sizeof(double));
+    if (best) memcpy(best, hs + 16, 3 * sizeof(double));
     return SLAM_OK;
 }
 

@@ -86,3 +86,65 @@ def essential_from_motion(R, t):
     tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
     E = R.T @ tx
     return E / np.linalg.norm(E)
+
+
+def make_track(n_known, n_matches, outlier_frac=0.2, seed=0, K=KITTI_K, size=KITTI_SIZE,
+               noise_px=0.5, noise_3d=0.05):
+    """Inputs of one tracking step (reference: custom_slam.py:229-252, src/triangulation.py:135-142).
+
+    The "previous" camera sits one unit step from the world origin and the "next" camera one further step;
+    ``n_known`` matches carry a (noisy) known 3D position, ``n_matches`` is the size of the full match list
+    (the known ones come first in it).  A fraction of the known matches gets a wrong next-image point.
+    Returns previous_pose (4x4), prev_known, next_known (n_known,2), X_known (n_known,3), prev_all, next_all
+    (n_matches,2), the true next pose and K.
+    """
+    assert n_matches >= n_known
+    rng = np.random.default_rng(seed)
+    w, h = size
+
+    def pose_of(R, t):
+        P = np.eye(4)
+        P[:3, :3] = R.T
+        P[:3, 3] = -R.T @ t
+        return P
+
+    R1 = _rotation(rng.normal(size=3), np.deg2rad(2.0) * rng.uniform(0.2, 1.0))
+    t1 = np.array([rng.normal(0, 0.1), rng.normal(0, 0.03), 1.0])
+    R2 = R1 @ _rotation(rng.normal(size=3), np.deg2rad(2.0) * rng.uniform(0.2, 1.0))
+    t2 = t1 + R1 @ np.array([rng.normal(0, 0.1), rng.normal(0, 0.03), 1.0])
+    Kinv = np.linalg.inv(K)
+    prev = np.empty((n_matches, 2))
+    nxt = np.empty((n_matches, 2))
+    X = np.empty((n_matches, 3))
+    filled = 0
+    while filled < n_matches:
+        m = (n_matches - filled) * 2 + 16
+        uv = np.column_stack([rng.uniform(0, w, m), rng.uniform(0, h, m), np.ones(m)])
+        depth = rng.uniform(5.0, 50.0, m)
+        q1 = (uv @ Kinv.T) * depth[:, None]           # previous-camera frame
+        P = q1 @ R1.T + t1                            # world
+        q2 = (P - t2) @ R2                            # next-camera frame
+        proj = q2 @ K.T
+        uv2 = proj[:, :2] / proj[:, 2:3]
+        ok = (q2[:, 2] > 1.0) & (uv2[:, 0] >= 0) & (uv2[:, 0] < w) & (uv2[:, 1] >= 0) & (uv2[:, 1] < h)
+        sel = np.flatnonzero(ok)[:n_matches - filled]
+        take = len(sel)
+        prev[filled:filled + take] = uv[sel, :2]
+        nxt[filled:filled + take] = uv2[sel]
+        X[filled:filled + take] = P[sel]
+        filled += take
+    prev += rng.normal(0, noise_px, prev.shape)
+    nxt += rng.normal(0, noise_px, nxt.shape)
+    X_known = X[:n_known] + rng.normal(0, noise_3d, (n_known, 3))
+    prev_known = prev[:n_known].copy()
+    next_known = nxt[:n_known].copy()
+    n_out = int(round(outlier_frac * n_known))
+    inlier = np.ones(n_known, dtype=bool)
+    if n_out:
+        out_idx = rng.choice(n_known, n_out, replace=False)
+        next_known[out_idx] = np.column_stack([rng.uniform(0, w, n_out), rng.uniform(0, h, n_out)])
+        nxt[out_idx] = next_known[out_idx]
+        inlier[out_idx] = False
+    return {"previous_pose": pose_of(R1, t1), "next_pose": pose_of(R2, t2), "prev_known": prev_known,
+            "next_known": next_known, "X_known": X_known, "prev_all": prev, "next_all": nxt,
+            "inlier": inlier, "K": np.array(K)}

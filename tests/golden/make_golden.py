@@ -222,11 +222,97 @@ def gen_pose():
         print(name, "cheirality counts", counts, buf.getvalue().strip())
 
 
+def quiet(fn, *a, **k):
+    """Call a reference function with its debugging prints swallowed."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def tracking_trace(d, iterations):
+    """Per-iteration quantities of the tracking RANSAC evaluated with the reference's own functions and
+    expressions (src/triangulation.py:153-176), plus the winner by its rule."""
+    a, b, X3, K, prev_pose = d["prev_known"], d["next_known"], d["X_known"], d["K"], d["previous_pose"]
+    M = len(X3)
+    H = min(iterations, math.comb(M, 6))
+    idx = np.empty((H, 6), dtype=np.int32)
+    poses = np.empty((H, 4, 4))
+    counts = np.empty(H, dtype=np.int32)
+    errs = np.empty(H)
+    best, best_err, best_i = -1, None, -1
+    for it in range(H):
+        ch = draw(M, it, 6)
+        idx[it] = ch
+        pose = quiet(triangulation.triangulate_pose_from_points, b[ch], X3[ch], K)
+        X = triangulation.triangulate_points_from_pose(K @ prev_pose[:3], K @ pose[:3], a, b)
+        R = util.pose_to_rotation(pose)
+        t = util.pose_to_translation(pose)
+        c2 = R @ np.asarray([0, 0, 1])
+        f1 = X[:, 2] > 0
+        f2 = np.dot((X - t), c2) > 0
+        c = np.count_nonzero(np.multiply(f1, f2))
+        e = np.sum(np.linalg.norm(X3 - X, axis=1))
+        poses[it], counts[it], errs[it] = pose, c, e
+        if c > best or (c == best and best_err > e):
+            best, best_err, best_i = c, e, it
+    return dict(idx=idx, poses=poses, counts=counts, errs=errs, best_index=np.int32(best_i),
+                best_count=np.int32(best), best_err=np.float64(best_err))
+
+
+def gen_tracking():
+    out = {}
+    # the 8 correspondences and intrinsics of the reference's own self-check (src/triangulation.py:188-206)
+    X8 = np.asarray([[6.03787985, -4.89579876, 62.66137844], [-8.39317134, 3.03552779, 18.92342537],
+                     [-15.53855632, -2.46611132, 92.2252502], [-2.58636809, 0.3066047, 20.0799362],
+                     [-16.17911693, -0.85989838, 44.88294597], [-18.83353488, -10.9979917, 71.92970211],
+                     [2.28097053, -0.6059205, 58.0935008], [3.27491554, -1.18588676, 85.08488668]])
+    uv8 = np.asarray([[783.60003662, 152.40000916], [142.56001282, 427.68002319], [513.60003662, 204.00001526],
+                      [504.5760498, 250.56002808], [299.52001953, 213.12001038], [413.2800293, 73.44000244],
+                      [726.58959961, 221.46052551], [727.38592529, 218.57409668]])
+    out["self_X"], out["self_uv"], out["self_K"] = X8, uv8, synth.REFERENCE_K
+    out["self_pose"] = quiet(triangulation.triangulate_pose_from_points, uv8, X8, synth.REFERENCE_K)
+    # single solves on 6, 7, 20 and 300 correspondences of a synthetic step
+    d = synth.make_track(300, 300, 0.0, 71)
+    for M in (6, 7, 20, 300):
+        out[f"solve_uv_{M}"], out[f"solve_X_{M}"] = d["next_known"][:M], d["X_known"][:M]
+        out[f"solve_pose_{M}"] = quiet(triangulation.triangulate_pose_from_points, d["next_known"][:M], d["X_known"][:M], d["K"])
+    r = np.array([[2.0, -1.0, 0.5], [0.3, 1.5, -0.7], [-0.2, 0.4, 1.1]])
+    out["rq_in"] = r
+    out["rq_r"], out["rq_q"] = util.rq_decomposition(r)
+    np.savez_compressed(os.path.join(HERE, "tracking_solve.npz"), **out)
+
+    cases = [("m6", 6, 40, 0.0, 72, 100), ("m7", 7, 40, 0.0, 73, 100), ("m40", 40, 200, 0.2, 74, 100),
+             ("m300", 300, 1000, 0.3, 75, 100)]
+    for name, M, N, frac, seed, iters in cases:
+        d = synth.make_track(M, N, frac, seed)
+        tr = tracking_trace(d, iters)
+        buf = io.StringIO()
+        logger.set_log_level("INFO")
+        with contextlib.redirect_stdout(buf):
+            pose, X = triangulation.triangulate_pose_from_points_with_ransac(
+                d["previous_pose"], d["prev_known"], d["next_known"], d["X_known"], d["prev_all"], d["next_all"],
+                d["K"], iterations=iters)
+        logger.set_log_level("WARN")
+        assert np.array_equal(pose, tr["poses"][tr["best_index"]]), name
+        log_line = [ln for ln in buf.getvalue().splitlines() if "Pose from points" in ln][-1]
+        np.savez_compressed(os.path.join(HERE, f"tracking_{name}.npz"), previous_pose=d["previous_pose"],
+                            prev_known=d["prev_known"], next_known=d["next_known"], X_known=d["X_known"],
+                            prev_all=d["prev_all"], next_all=d["next_all"], K=d["K"], true_next_pose=d["next_pose"],
+                            iterations=np.int32(iters), pose=pose, X=X, log_line=np.array(log_line), **tr)
+        print(name, "H", len(tr["counts"]), "winner", int(tr["best_index"]), "count", int(tr["best_count"]),
+              "err", float(tr["best_err"]), log_line)
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:
+        for name in only:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_sampler()
     gen_normalize()
     gen_solve()
     gen_ransac()
     gen_triangulate()
     gen_pose()
+    gen_tracking()
     print("python", sys.version.split()[0], "numpy", np.__version__)

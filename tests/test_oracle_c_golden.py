@@ -4,6 +4,7 @@ import pytest
 
 from conftest import fix_sign_scale, load_golden, rel_err
 from oracle import c_oracle as co
+from oracle import slam_oracle as so
 
 
 def point_err(X, ref):
@@ -83,3 +84,30 @@ def test_pose(name):
     for k in range(4):
         d = [np.abs(Rs[k] - g["cand_R"][j]).max() + np.abs(ts[k] - g["cand_t"][j]).max() for j in range(4)]
         assert min(d) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------- tracking step
+def test_c_pose_from_points_self_check_fixture():
+    g = load_golden("tracking_solve")
+    pose, extra = co.pose_from_points(g["self_uv"], g["self_X"], want_extra=True)
+    assert rel_err(pose, g["self_pose"]) < 1e-8
+    want = so.pose_from_points_detailed(g["self_uv"], g["self_X"])
+    for key in ("K", "R", "t", "centre"):
+        assert rel_err(extra[key], want[key]) < 1e-8, key
+
+
+@pytest.mark.parametrize("M", (6, 7, 20, 300))
+def test_c_pose_from_points_matches_golden(M):
+    g = load_golden("tracking_solve")
+    assert rel_err(co.pose_from_points(g[f"solve_uv_{M}"], g[f"solve_X_{M}"]), g[f"solve_pose_{M}"]) < 1e-8
+
+
+@pytest.mark.parametrize("name", ("m6", "m7", "m40", "m300"))
+def test_c_tracking_ransac_matches_golden(name):
+    g = load_golden("tracking_" + name)
+    r = co.tracking_ransac(g["previous_pose"], g["prev_known"], g["next_known"], g["X_known"], g["K"], g["idx"])
+    assert np.array_equal(r["counts"], g["counts"])
+    assert np.max(np.abs(r["errs"] / g["errs"] - 1)) < 1e-6
+    assert r["best_index"] == int(g["best_index"])
+    for h in range(len(g["idx"])):
+        assert rel_err(r["poses"][h], g["poses"][h]) < 1e-6, h

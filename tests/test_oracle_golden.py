@@ -107,3 +107,49 @@ def test_full_pair(name):
     r = so.initialise_pair(g["pts0"], g["pts1"], g["K"])
     assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(g["F"])) < 1e-8
     assert np.array_equal(r["cheirality"], g["cand_counts"])
+
+
+# ---------------------------------------------------------------------------------------------- tracking step
+TRACK_CASES = ("m6", "m7", "m40", "m300")
+
+
+def test_rq_decomposition_matches_reference():
+    g = load_golden("tracking_solve")
+    r, q = so.rq_decomposition(g["rq_in"])
+    assert np.allclose(r, g["rq_r"], rtol=0, atol=1e-14) and np.allclose(q, g["rq_q"], rtol=0, atol=1e-14)
+    # the reference's function does not factor its argument: r @ q is the argument transposed about the anti-diagonal
+    J = np.rot90(np.eye(3))
+    assert np.allclose(r @ q, J @ g["rq_in"].T @ J)
+
+
+def test_pose_from_points_self_check_fixture():
+    g = load_golden("tracking_solve")
+    assert rel_err(so.pose_from_points(g["self_uv"], g["self_X"]), g["self_pose"]) < 1e-9
+
+
+@pytest.mark.parametrize("M", (6, 7, 20, 300))
+def test_pose_from_points_matches_golden(M):
+    g = load_golden("tracking_solve")
+    assert rel_err(so.pose_from_points(g[f"solve_uv_{M}"], g[f"solve_X_{M}"]), g[f"solve_pose_{M}"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", TRACK_CASES)
+def test_tracking_ransac_matches_golden(name):
+    g = load_golden("tracking_" + name)
+    r = so.pose_from_points_ransac(g["previous_pose"], g["prev_known"], g["next_known"], g["X_known"], g["prev_all"],
+                                   g["next_all"], g["K"], int(g["iterations"]))
+    assert np.array_equal(r["idx"], g["idx"])
+    assert np.array_equal(r["counts"], g["counts"])
+    assert np.max(np.abs(r["errs"] / g["errs"] - 1)) < 1e-9
+    assert r["best_index"] == int(g["best_index"]) and r["best_count"] == int(g["best_count"])
+    assert rel_err(r["pose"], g["pose"]) < 1e-9
+    assert rel_err(r["X"], g["X"]) < 1e-9
+
+
+def test_tracking_asserts():
+    g = load_golden("tracking_m6")
+    with pytest.raises(AssertionError):
+        so.pose_from_points(g["next_known"][:5], g["X_known"][:5])
+    with pytest.raises(AssertionError):
+        so.pose_from_points_ransac(g["previous_pose"], g["prev_known"][:5], g["next_known"][:5], g["X_known"][:5],
+                                   g["prev_all"], g["next_all"], g["K"])

@@ -159,6 +159,28 @@ int slam_track_pose_dev(slam_ctx* ctx, const double* previous_pose, const double
                         const double* d_next_all, int64_t N, const double* K, int iterations, double* d_pose,
                         double* d_X, double* d_best);
 
+/* ---- descriptor matching: custom_slam.py:14-26, 56-82 --------------------------------------------- */
+/* Descriptors are packed 256-bit strings, 32 bytes each (what ORB emits; the reference unpacks them to one byte
+ * per bit before matching, custom_slam.py:51, which changes nothing in the distances).  At most 2^22 train
+ * descriptors.
+ * custom_slam.py:14-26 match_knn_brute_force with num_matches = k (1 or 2): index, distance are (n0, k) int32, nearest
+ * first, equal distances in ascending train index (the reference's stable sort); -1 where n1 < k. */
+int slam_match_knn(slam_ctx* ctx, const uint8_t* des0, int n0, const uint8_t* des1, int n1, int k, int32_t* index,
+                   int32_t* distance);
+/* custom_slam.py:60-73: 2-NN of every descriptor of image 0 among those of image 1, the ratio test
+ * (best distance < 0.5 * second best) and the matched point lists, in image-0 keypoint order.
+ * pts0 (n0,2), pts1 (n1,2): keypoint coordinates.  matched0/matched1: room for (n0,2) each; *n_matched rows are
+ * written.  index/distance: (n0,2) int32 2-NN results, may be NULL. */
+int slam_match_points(slam_ctx* ctx, const uint8_t* des0, const double* pts0, int n0, const uint8_t* des1,
+                      const double* pts1, int n1, double* matched0, double* matched1, int32_t* n_matched,
+                      int32_t* index, int32_t* distance);
+/* same with device pointers (descriptor pointers 16-byte aligned), asynchronous on the context's stream;
+ * d_n_matched: one int32 on the device.  The matched lists can go straight into slam_ransac_f_dev once the count
+ * has been read back. */
+int slam_match_points_dev(slam_ctx* ctx, const uint8_t* d_des0, const double* d_pts0, int n0, const uint8_t* d_des1,
+                          const double* d_pts1, int n1, double* d_matched0, double* d_matched1, int32_t* d_n_matched,
+                          int32_t* d_index, int32_t* d_distance);
+
 /* ---- kernel timing for benchmarks ---------------------------------------------------------------- */
 #define SLAM_K_SOLVE 0
 #define SLAM_K_SCORE 1
@@ -166,7 +188,8 @@ int slam_track_pose_dev(slam_ctx* ctx, const double* previous_pose, const double
 #define SLAM_K_TRIANGULATE 3
 #define SLAM_K_RESECT 4
 #define SLAM_K_TRACK_SCORE 5
-#define SLAM_K_COUNT 6
+#define SLAM_K_MATCH 6
+#define SLAM_K_COUNT 7
 /* When enabled, every launch of the kernels above is bracketed by HIP events on the context's stream. */
 int slam_profile_enable(slam_ctx* ctx, int on);
 /* Synchronises, then returns total milliseconds and number of launches recorded for `kernel` since the last reset. */

@@ -41,6 +41,9 @@ def lib():
         L.oracle_pose_from_points.argtypes = [_f64, _f64, C.c_int, _f64, C.c_void_p]
         L.oracle_tracking_ransac.argtypes = [_f64, _f64, _f64, _f64, C.c_int, _f64, _i32, C.c_int, _f64, _i32, _f64,
                                              C.POINTER(C.c_int32)]
+        _u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        L.oracle_match_knn.argtypes = [_u8, _u8, C.c_int, C.c_int, C.c_int, _i32, _i32]
+        L.oracle_select_matches.argtypes = [_f64, _f64, _i32, _i32, C.c_int, _f64, _f64]
         _LIB = L
     return _LIB
 
@@ -139,3 +142,21 @@ def tracking_ransac(previous_pose, prev_known, next_known, known_3d_points, K, i
                                       C.byref(bi))
     assert rc == 0
     return dict(poses=poses, counts=counts, errs=errs, best_index=int(bi.value), pose=poses[bi.value])
+
+
+def match_knn(des0, des1, k=2):
+    des0, des1 = _c(des0, np.uint8), _c(des1, np.uint8)
+    assert des0.shape[1] == 32 and des1.shape[1] == 32
+    index = np.empty((len(des0), k), dtype=np.int32)
+    distance = np.empty((len(des0), k), dtype=np.int32)
+    assert lib().oracle_match_knn(des0, des1, len(des0), len(des1), k, index, distance) == 0
+    return index, distance
+
+
+def select_matches(pts0, pts1, index, distance):
+    pts0, pts1 = _c(pts0), _c(pts1)
+    index, distance = _c(index, np.int32), _c(distance, np.int32)
+    m0 = np.empty((len(pts0), 2))
+    m1 = np.empty((len(pts0), 2))
+    n = lib().oracle_select_matches(pts0, pts1, index, distance, len(pts0), m0, m1)
+    return m0[:n].copy(), m1[:n].copy()

@@ -568,3 +568,52 @@ int oracle_tracking_ransac(const double* prev_pose, const double* a, const doubl
     *best = bi;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * descriptor matching: custom_slam.py:14-26 (brute-force Hamming k-NN, stable order) and :62-73 (ratio test)
+ * des0: n0 x 32 bytes, des1: n1 x 32 bytes (packed 256-bit descriptors).  index/distance: n0 x k, entries beyond
+ * the number of train descriptors are -1.
+ * ---------------------------------------------------------------------------------- */
+int oracle_match_knn(const uint8_t* des0, const uint8_t* des1, int n0, int n1, int k, int32_t* index, int32_t* distance) {
+    if (k < 1 || k > 16) return -1;
+    for (int q = 0; q < n0; q++) {
+        int32_t bi[16], bd[16];
+        int have = 0;
+        uint64_t a[4];
+        memcpy(a, des0 + 32 * (size_t)q, 32);
+        for (int j = 0; j < n1; j++) {
+            uint64_t b[4];
+            memcpy(b, des1 + 32 * (size_t)j, 32);
+            int32_t d = 0;
+            for (int w = 0; w < 4; w++) d += __builtin_popcountll(a[w] ^ b[w]);                 /* :21 */
+            /* insertion keeps ascending (distance, index): a later equal distance never overtakes  :23 */
+            int pos = have;
+            while (pos > 0 && d < bd[pos - 1]) pos--;
+            if (pos >= k) continue;
+            const int last = have < k ? have : k - 1;
+            for (int m = last; m > pos; m--) { bd[m] = bd[m - 1]; bi[m] = bi[m - 1]; }
+            bd[pos] = d; bi[pos] = j;
+            if (have < k) have++;
+        }
+        for (int m = 0; m < k; m++) {
+            index[(size_t)q * k + m] = m < have ? bi[m] : -1;
+            distance[(size_t)q * k + m] = m < have ? bd[m] : -1;
+        }
+    }
+    return 0;
+}
+
+/* returns the number of matches kept; m0/m1: up to n0 x 2 */
+int oracle_select_matches(const double* pts0, const double* pts1, const int32_t* index, const int32_t* distance, int n0,
+                          double* m0, double* m1) {
+    int kept = 0;
+    for (int q = 0; q < n0; q++) {
+        if ((double)distance[2 * q] < 0.5 * (double)distance[2 * q + 1]) {                      /* :67 */
+            const int32_t j = index[2 * q];
+            m0[2 * kept] = pts0[2 * q]; m0[2 * kept + 1] = pts0[2 * q + 1];
+            m1[2 * kept] = pts1[2 * j]; m1[2 * kept + 1] = pts1[2 * j + 1];
+            kept++;
+        }
+    }
+    return kept;
+}

@@ -19,7 +19,7 @@ REC_COUNT, REC_ERRSUM, REC_INDEX, REC_F, REC_LEN = 0, 1, 2, 3, 12
 SAMPLER_CPYTHON, SAMPLER_COUNTER = 0, 1
 SEED_BASE = 0x1337BEEF
 DEFAULT_THRESHOLD = 0.005
-K_SOLVE, K_SCORE, K_SELECT, K_TRIANGULATE, K_RESECT, K_TRACK_SCORE = 0, 1, 2, 3, 4, 5
+K_SOLVE, K_SCORE, K_SELECT, K_TRIANGULATE, K_RESECT, K_TRACK_SCORE, K_MATCH = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/slam_amd.h declares, with its ctypes signature
 _vp, _i32, _i64, _u64, _f64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_int
@@ -48,6 +48,9 @@ SIGNATURES = {
     "slam_pose_from_points": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
     "slam_track_pose": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "slam_track_pose_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
+    "slam_match_knn": (_int, [_vp, _vp, _int, _vp, _int, _int, _vp, _vp]),
+    "slam_match_points": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    "slam_match_points_dev": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "slam_profile_enable": (_int, [_vp, _int]),
     "slam_profile_read": (_int, [_vp, _int, C.POINTER(_f64), C.POINTER(_i64)]),
     "slam_profile_reset": (_int, [_vp]),

@@ -11,6 +11,7 @@
 #include "kernels_ransac.h"
 #include "kernels_tri.h"
 #include "kernels_track.h"
+#include "kernels_match.h"
 
 using namespace slamk;
 
@@ -82,7 +83,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)slam_sync_all(ctx);
     slam_buf* bufs[] = {&ctx->pts, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
-                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track};
+                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track, &ctx->match};
     for (slam_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int l = 0; l < SLAM_LANES; ++l) {
@@ -848,6 +849,117 @@ extern "C" int slam_track_pose(slam_ctx* ctx, const double* previous_pose, const
     SLAM_TRY(check_flags(ctx));
     memcpy(pose, hs, 16 * sizeof(double));
     if (best) memcpy(best, hs + 16, 3 * sizeof(double));
+    return SLAM_OK;
+}
+
+// ================================================================================================
+// descriptor matching
+// ================================================================================================
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// number of train slices: enough workgroups to cover the chip, slices of at least 256 descriptors
+static int match_slices(int n0, int n1) {
+    const int qblocks = (n0 + 63) / 64;
+    int s = (256 + qblocks - 1) / qblocks;
+    s = std::min(s, (n1 + 255) / 256);
+    return std::max(1, std::min(s, 64));
+}
+
+// d_part: n0 * slices * 2 uint32
+static int match_enqueue(slam_ctx* ctx, const uint8_t* d_des0, const double* d_pts0, int n0, const uint8_t* d_des1,
+                         const double* d_pts1, int n1, int slices, uint32_t* d_part, double* d_m0, double* d_m1,
+                         int32_t* d_n, int32_t* d_index, int32_t* d_distance) {
+    const int per_slice = (n1 + slices - 1) / slices;
+    SLAM_TRY(slam_launch(ctx, SLAM_K_MATCH, k_match_knn2, dim3((n0 + 63) / 64, slices), dim3(256), 0,
+                         (const uint32_t*)d_des0, (const uint32_t*)d_des1, n0, n1, per_slice, d_part));
+    SLAM_TRY(slam_launch(ctx, -1, k_match_finish, dim3(1), dim3(1024), 0, (const uint32_t*)d_part, slices, n0,
+                         (const double2*)d_pts0, (const double2*)d_pts1, d_index, d_distance, (double2*)d_m0,
+                         (double2*)d_m1, d_n));
+    return SLAM_OK;
+}
+
+#define SLAM_MATCH_ARGS_OK(ctx, n0, n1)                                                              \
+    SLAM_REQUIRE(ctx, (n0) >= 1 && (n1) >= 1, "empty descriptor set");                               \
+    SLAM_REQUIRE(ctx, (n1) <= SLAM_MATCH_MAX_TRAIN, "more than 2^22 train descriptors")
+
+extern "C" int slam_match_points_dev(slam_ctx* ctx, const uint8_t* d_des0, const double* d_pts0, int n0,
+                                     const uint8_t* d_des1, const double* d_pts1, int n1, double* d_matched0,
+                                     double* d_matched1, int32_t* d_n_matched, int32_t* d_index, int32_t* d_distance) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, d_des0 && d_des1 && d_pts0 && d_pts1 && d_matched0 && d_matched1 && d_n_matched, "NULL pointer");
+    SLAM_MATCH_ARGS_OK(ctx, n0, n1);
+    SLAM_REQUIRE(ctx, ((uintptr_t)d_des0 & 15) == 0 && ((uintptr_t)d_des1 & 15) == 0, "descriptor pointers must be 16-byte aligned");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int slices = match_slices(n0, n1);
+    SLAM_TRY(slam_reserve(ctx, ctx->match, (size_t)n0 * slices * 2 * sizeof(uint32_t)));
+    return match_enqueue(ctx, d_des0, d_pts0, n0, d_des1, d_pts1, n1, slices, (uint32_t*)ctx->match.p, d_matched0,
+                         d_matched1, d_n_matched, d_index, d_distance);
+}
+
+// host form shared by slam_match_knn (no points) and slam_match_points
+static int match_host(slam_ctx* ctx, const uint8_t* des0, const double* pts0, int n0, const uint8_t* des1,
+                      const double* pts1, int n1, double* matched0, double* matched1, int32_t* n_matched, int32_t* index,
+                      int32_t* distance) {
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int slices = match_slices(n0, n1);
+    const bool gather = pts0 != nullptr;
+    const size_t b_part = align256((size_t)n0 * slices * 2 * sizeof(uint32_t));
+    const size_t b_d0 = align256((size_t)n0 * 32), b_d1 = align256((size_t)n1 * 32);
+    const size_t b_p0 = gather ? align256((size_t)n0 * 16) : 0, b_p1 = gather ? align256((size_t)n1 * 16) : 0;
+    const size_t b_m = gather ? align256((size_t)n0 * 16) : 0, b_i = align256((size_t)n0 * 2 * sizeof(int32_t));
+    SLAM_TRY(slam_reserve(ctx, ctx->match, b_part + b_d0 + b_d1 + b_p0 + b_p1 + 2 * b_m + 2 * b_i + 256));
+    char* at = (char*)ctx->match.p;
+    auto take = [&](size_t bytes) { char* p = at; at += bytes; return p; };
+    uint32_t* d_part = (uint32_t*)take(b_part);
+    uint8_t* d_d0 = (uint8_t*)take(b_d0);
+    uint8_t* d_d1 = (uint8_t*)take(b_d1);
+    double* d_p0 = gather ? (double*)take(b_p0) : nullptr;
+    double* d_p1 = gather ? (double*)take(b_p1) : nullptr;
+    double* d_m0 = gather ? (double*)take(b_m) : nullptr;
+    double* d_m1 = gather ? (double*)take(b_m) : nullptr;
+    int32_t* d_index = (int32_t*)take(b_i);
+    int32_t* d_distance = (int32_t*)take(b_i);
+    int32_t* d_n = (int32_t*)take(256);
+    SLAM_HIP(ctx, hipMemcpyAsync(d_d0, des0, (size_t)n0 * 32, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(d_d1, des1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (gather) {
+        SLAM_HIP(ctx, hipMemcpyAsync(d_p0, pts0, (size_t)n0 * 16, hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(d_p1, pts1, (size_t)n1 * 16, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SLAM_TRY(match_enqueue(ctx, d_d0, d_p0, n0, d_d1, d_p1, n1, slices, d_part, d_m0, d_m1, d_n, d_index, d_distance));
+    int32_t* h_n = (int32_t*)(ctx->h_small + 128);
+    SLAM_HIP(ctx, hipMemcpyAsync(h_n, d_n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (index) SLAM_HIP(ctx, hipMemcpyAsync(index, d_index, (size_t)n0 * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (distance) SLAM_HIP(ctx, hipMemcpyAsync(distance, d_distance, (size_t)n0 * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_matched) *n_matched = *h_n;
+    if (gather && *h_n > 0) {
+        SLAM_HIP(ctx, hipMemcpyAsync(matched0, d_m0, (size_t)*h_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(matched1, d_m1, (size_t)*h_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SLAM_OK;
+}
+
+extern "C" int slam_match_points(slam_ctx* ctx, const uint8_t* des0, const double* pts0, int n0, const uint8_t* des1,
+                                 const double* pts1, int n1, double* matched0, double* matched1, int32_t* n_matched,
+                                 int32_t* index, int32_t* distance) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, des0 && des1 && pts0 && pts1 && matched0 && matched1 && n_matched, "NULL pointer");
+    SLAM_MATCH_ARGS_OK(ctx, n0, n1);
+    return match_host(ctx, des0, pts0, n0, des1, pts1, n1, matched0, matched1, n_matched, index, distance);
+}
+
+extern "C" int slam_match_knn(slam_ctx* ctx, const uint8_t* des0, int n0, const uint8_t* des1, int n1, int k,
+                              int32_t* index, int32_t* distance) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, des0 && des1 && index && distance, "NULL pointer");
+    SLAM_REQUIRE(ctx, k == 1 || k == 2, "k must be 1 or 2");
+    SLAM_MATCH_ARGS_OK(ctx, n0, n1);
+    if (k == 2) return match_host(ctx, des0, nullptr, n0, des1, nullptr, n1, nullptr, nullptr, nullptr, index, distance);
+    std::vector<int32_t> i2((size_t)n0 * 2), d2((size_t)n0 * 2);
+    SLAM_TRY(match_host(ctx, des0, nullptr, n0, des1, nullptr, n1, nullptr, nullptr, nullptr, i2.data(), d2.data()));
+    for (int q = 0; q < n0; ++q) { index[q] = i2[2 * (size_t)q]; distance[q] = d2[2 * (size_t)q]; }
     return SLAM_OK;
 }
 

@@ -302,6 +302,58 @@ def gen_tracking():
               "err", float(tr["best_err"]), log_line)
 
 
+def synth_descriptors(n0, n1, n_true, flip_bits, seed, distinct=None):
+    """Unpacked 256-bit descriptors (0/1 uint8, as custom_slam.py:51 produces them): n_true of the n0 queries have a
+    counterpart in the train set that differs in about flip_bits bits; `distinct` limits the number of different
+    descriptors to force ties."""
+    rng = np.random.default_rng(seed)
+    if distinct:
+        base = rng.integers(0, 2, (distinct, 256), dtype=np.uint8)
+        d0 = base[rng.integers(0, distinct, n0)]
+        d1 = base[rng.integers(0, distinct, n1)]
+        return d0, d1
+    d0 = rng.integers(0, 2, (n0, 256), dtype=np.uint8)
+    d1 = rng.integers(0, 2, (n1, 256), dtype=np.uint8)
+    where = rng.choice(n1, n_true, replace=False)
+    for q, j in enumerate(where):
+        d = d0[q].copy()
+        d[rng.choice(256, flip_bits, replace=False)] ^= 1
+        d1[j] = d
+    return d0, d1
+
+
+def gen_matching():
+    out = {}
+    cases = [("rand", 40, 50, 25, 20, 91, None), ("ties", 30, 45, 0, 0, 92, 6), ("wide", 70, 33, 20, 40, 93, None),
+             ("two", 5, 2, 2, 10, 94, None)]
+    for name, n0, n1, n_true, flips, seed, distinct in cases:
+        d0, d1 = synth_descriptors(n0, n1, n_true, flips, seed, distinct)
+        rng = np.random.default_rng(seed + 1000)
+        pts0 = rng.uniform(0, 1000, (n0, 2))
+        pts1 = rng.uniform(0, 1000, (n1, 2))
+        knn = custom_slam.match_knn_brute_force(d0, d1, 2)
+        # the selection loop of custom_slam.py:62-73 applied to the reference's own k-NN result
+        m0, m1 = [], []
+        for idx, (m, n) in enumerate(knn):
+            if m["distance"] < 0.5 * n["distance"]:
+                m0.append(pts0[idx])
+                m1.append(pts1[m["index"]])
+        out[f"{name}_des0"], out[f"{name}_des1"] = np.packbits(d0, axis=1), np.packbits(d1, axis=1)
+        out[f"{name}_pts0"], out[f"{name}_pts1"] = pts0, pts1
+        out[f"{name}_knn_index"] = np.array([[e["index"] for e in row] for row in knn], dtype=np.int32)
+        out[f"{name}_knn_distance"] = np.array([[e["distance"] for e in row] for row in knn], dtype=np.int32)
+        out[f"{name}_matched0"] = np.asarray(m0).reshape(-1, 2)
+        out[f"{name}_matched1"] = np.asarray(m1).reshape(-1, 2)
+        print("matching", name, "queries", n0, "train", n1, "kept", len(m0))
+    # k = 3 on one case: the function takes any k
+    d0, d1 = synth_descriptors(12, 20, 6, 25, 95)
+    knn = custom_slam.match_knn_brute_force(d0, d1, 3)
+    out["k3_des0"], out["k3_des1"] = np.packbits(d0, axis=1), np.packbits(d1, axis=1)
+    out["k3_knn_index"] = np.array([[e["index"] for e in row] for row in knn], dtype=np.int32)
+    out["k3_knn_distance"] = np.array([[e["distance"] for e in row] for row in knn], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "matching.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -315,4 +367,5 @@ if __name__ == "__main__":
     gen_triangulate()
     gen_pose()
     gen_tracking()
+    gen_matching()
     print("python", sys.version.split()[0], "numpy", np.__version__)

@@ -1,0 +1,109 @@
+"""Parity of the descriptor matcher on the GPU, through the C ABI, with golden vectors captured from the reference's
+brute-force matcher (custom_slam.py:14-26) and its ratio-test loop (:62-73), and with the CPU restatements on larger
+inputs.  Everything here is integer or gathered data: compared exactly."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import c_oracle as co
+from oracle import slam_oracle as so
+from slam_amd import _lib, logger, matching
+
+pytestmark = pytest.mark.gpu
+CASES = ("rand", "ties", "wide", "two")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    logger.set_log_level("WARN")
+    return _lib.default_context()
+
+
+def random_descriptors(n0, n1, n_true, flips, seed):
+    rng = np.random.default_rng(seed)
+    d0 = rng.integers(0, 256, (n0, 32), dtype=np.uint8)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    where = rng.choice(n1, n_true, replace=False)
+    bits = np.unpackbits(d0[:n_true], axis=1)
+    for q in range(n_true):
+        bits[q, rng.choice(256, flips, replace=False)] ^= 1
+    d1[where] = np.packbits(bits, axis=1)
+    return d0, d1
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_knn_matches_golden(ctx, name):
+    g = load_golden("matching")
+    index, distance = matching.knn(g[name + "_des0"], g[name + "_des1"], 2, ctx)
+    assert np.array_equal(index, g[name + "_knn_index"])
+    assert np.array_equal(distance, g[name + "_knn_distance"])
+    i1, d1 = matching.knn(g[name + "_des0"], g[name + "_des1"], 1, ctx)
+    assert np.array_equal(i1[:, 0], g[name + "_knn_index"][:, 0]) and np.array_equal(d1[:, 0], g[name + "_knn_distance"][:, 0])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_matched_points_match_golden(ctx, name):
+    g = load_golden("matching")
+    m0, m1 = matching.matches_between_keypoints(g[name + "_pts0"], g[name + "_des0"], g[name + "_pts1"], g[name + "_des1"], ctx)
+    assert np.array_equal(m0, g[name + "_matched0"])
+    assert np.array_equal(m1, g[name + "_matched1"])
+
+
+def test_reference_structure_and_unpacked_input(ctx):
+    g = load_golden("matching")
+    bits0, bits1 = np.unpackbits(g["rand_des0"], axis=1), np.unpackbits(g["rand_des1"], axis=1)
+    out = matching.match_knn_brute_force(bits0, bits1, 2, ctx)
+    assert len(out) == len(bits0) and all(len(row) == 2 for row in out)
+    assert [row[0]["index"] for row in out] == g["rand_knn_index"][:, 0].tolist()
+    assert [row[1]["distance"] for row in out] == g["rand_knn_distance"][:, 1].tolist()
+
+
+def test_single_train_descriptor(ctx):
+    g = load_golden("matching")
+    out = matching.match_knn_brute_force(g["rand_des0"], g["rand_des1"][:1], 2, ctx)
+    assert all(len(row) == 1 and row[0]["index"] == 0 for row in out)
+    m0, m1 = matching.matches_between_keypoints(g["rand_pts0"], g["rand_des0"], g["rand_pts1"][:1], g["rand_des1"][:1], ctx)
+    assert len(m0) == 0 and len(m1) == 0
+
+
+@pytest.mark.parametrize("n0,n1", [(4096, 4096), (1000, 3001), (70, 9000), (5000, 257)])
+def test_larger_sets_against_c_restatement(ctx, n0, n1):
+    d0, d1 = random_descriptors(n0, n1, min(n0, n1) // 2, 30, seed=n0 + n1)
+    rng = np.random.default_rng(1)
+    p0, p1 = rng.uniform(0, 1000, (n0, 2)), rng.uniform(0, 1000, (n1, 2))
+    m0, m1, index, distance = matching.matches_between_keypoints(p0, d0, p1, d1, ctx, return_knn=True)
+    wi, wd = co.match_knn(d0, d1, 2)
+    assert np.array_equal(index, wi) and np.array_equal(distance, wd)
+    w0, w1 = co.select_matches(p0, p1, wi, wd)
+    assert np.array_equal(m0, w0) and np.array_equal(m1, w1)
+    assert len(m0) >= min(n0, n1) // 2 - 5            # the planted counterparts pass the ratio test
+
+
+def test_many_ties_keep_ascending_index(ctx):
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+    d0 = base[rng.integers(0, 4, 300)]
+    d1 = base[rng.integers(0, 4, 2000)]
+    index, distance = matching.knn(d0, d1, 2, ctx)
+    wi, wd = so.match_knn_brute_force(d0, d1, 2)
+    assert np.array_equal(index, wi) and np.array_equal(distance, wd)
+
+
+def test_device_entry_point(ctx):
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    d0, d1 = random_descriptors(3000, 2500, 1200, 25, seed=9)
+    rng = np.random.default_rng(2)
+    p0, p1 = rng.uniform(0, 1000, (3000, 2)), rng.uniform(0, 1000, (2500, 2))
+    t = [torch.from_numpy(x).to(dev) for x in (d0, p0, d1, p1)]
+    m0 = torch.empty((3000, 2), dtype=torch.float64, device=dev)
+    m1 = torch.empty((3000, 2), dtype=torch.float64, device=dev)
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.slam_match_points_dev(ctx.handle, t[0].data_ptr(), t[1].data_ptr(), 3000, t[2].data_ptr(), t[3].data_ptr(),
+                                            2500, m0.data_ptr(), m1.data_ptr(), n.data_ptr(), None, None))
+    ctx.check(ctx.lib.slam_synchronize(ctx.handle))
+    h0, h1 = matching.matches_between_keypoints(p0, d0, p1, d1, ctx)
+    k = int(n.item())
+    assert k == len(h0)
+    assert np.array_equal(m0[:k].cpu().numpy(), h0) and np.array_equal(m1[:k].cpu().numpy(), h1)

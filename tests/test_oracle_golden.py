@@ -153,3 +153,25 @@ def test_tracking_asserts():
     with pytest.raises(AssertionError):
         so.pose_from_points_ransac(g["previous_pose"], g["prev_known"][:5], g["next_known"][:5], g["X_known"][:5],
                                    g["prev_all"], g["next_all"], g["K"])
+
+
+# ---------------------------------------------------------------------------------------------- descriptor matching
+@pytest.mark.parametrize("name", ("rand", "ties", "wide", "two"))
+def test_matching_restatements_match_golden(name):
+    from oracle import c_oracle as co
+    g = load_golden("matching")
+    for impl in (so.match_knn_brute_force, co.match_knn):
+        index, distance = impl(g[name + "_des0"], g[name + "_des1"], 2)
+        assert np.array_equal(index, g[name + "_knn_index"]) and np.array_equal(distance, g[name + "_knn_distance"])
+    m0, m1, _ = so.select_matches(g[name + "_pts0"], g[name + "_pts1"], g[name + "_knn_index"], g[name + "_knn_distance"])
+    assert np.array_equal(m0, g[name + "_matched0"]) and np.array_equal(m1, g[name + "_matched1"])
+    c0, c1 = co.select_matches(g[name + "_pts0"], g[name + "_pts1"], g[name + "_knn_index"], g[name + "_knn_distance"])
+    assert np.array_equal(c0, m0) and np.array_equal(c1, m1)
+
+
+def test_matching_three_nearest():
+    from oracle import c_oracle as co
+    g = load_golden("matching")
+    for impl in (so.match_knn_brute_force, co.match_knn):
+        index, distance = impl(g["k3_des0"], g["k3_des1"], 3)
+        assert np.array_equal(index, g["k3_knn_index"]) and np.array_equal(distance, g["k3_knn_distance"])

@@ -14,6 +14,7 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
                 launch on the library's stream during a second timed pass of K steps
   cpu_baseline  the C restatement in oracle/ timed on this host's cores (rank 0, N=1 only)
   aux_tracking  the tracking step (pose from 2D-3D matches + its 100-hypothesis loop), one call per step
+  aux_matching  Hamming 2-NN descriptor matching with ratio test, 4096 x 4096 descriptors
   aux           bulk triangulation + cheirality throughput (4 candidates per point) with its own roofline
 """
 import argparse
@@ -358,6 +359,64 @@ def main():
             co.triangulate(tr["previous_pose"], ow["pose"], tr["prev_all"], tr["next_all"])
             out["aux_tracking"]["cpu_port_us_per_step"] = (time.perf_counter() - t1) * 1e6
             out["aux_tracking"]["winner_matches_cpu"] = bool(ow["best_index"] == int(t_best[0].item()))
+
+    # ---- aux: descriptor matching (Hamming 2-NN + ratio test + gathering), descriptors resident in HBM
+    if not args.no_aux:
+        NQ = NTR = 4096
+        rng = np.random.default_rng(11)
+        des0 = rng.integers(0, 256, (NQ, 32), dtype=np.uint8)
+        des1 = rng.integers(0, 256, (NTR, 32), dtype=np.uint8)
+        bits = np.unpackbits(des0[:NQ // 2], axis=1)
+        for qi in range(NQ // 2):
+            bits[qi, rng.choice(256, 30, replace=False)] ^= 1
+        des1[rng.choice(NTR, NQ // 2, replace=False)] = np.packbits(bits, axis=1)
+        kp0, kp1 = rng.uniform(0, 1000, (NQ, 2)), rng.uniform(0, 1000, (NTR, 2))
+        mt = [torch.from_numpy(x).to(dev) for x in (des0, kp0, des1, kp1)]
+        mm0 = torch.empty((NQ, 2), dtype=torch.float64, device=dev)
+        mm1 = torch.empty((NQ, 2), dtype=torch.float64, device=dev)
+        mn = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def match_step():
+            ctx.check(lib.slam_match_points_dev(ctx.handle, mt[0].data_ptr(), mt[1].data_ptr(), NQ, mt[2].data_ptr(),
+                                                mt[3].data_ptr(), NTR, mm0.data_ptr(), mm1.data_ptr(), mn.data_ptr(), None, None))
+
+        for _ in range(3):
+            match_step()
+        barrier()
+        msteps = 50
+        t0 = time.perf_counter()
+        for _ in range(msteps):
+            match_step()
+        barrier()
+        mdt_ = (time.perf_counter() - t0) / msteps
+        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+        ctx.check(lib.slam_profile_reset(ctx.handle))
+        for _ in range(msteps):
+            match_step()
+        ms, n = C.c_double(0), C.c_int64(0)
+        ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_MATCH, C.byref(ms), C.byref(n)))
+        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+        k_us = 1e3 * ms.value / max(n.value, 1)
+        pairs = NQ * NTR
+        # issue bound of the inner loop: 20 vector integer instructions per (query, train) pair and lane, one wave
+        # instruction per 4 cycles and SIMD, 1024 SIMDs at 2.4 GHz
+        peak_pairs = 1024 * 2.4e9 / (4 * 20) * 64
+        out["aux_matching"] = {"workload": f"{NQ} x {NTR} 256-bit descriptors: Hamming 2-NN, ratio test, ordered gathering of the kept matches",
+                               "us_per_step": mdt_ * 1e6, "descriptor_pairs_per_sec": world * pairs / mdt_,
+                               "kept_matches": int(mn.item()),
+                               "roofline": {"kernel": "k_match_knn2", "bound": "valu_int", "achieved": pairs / (k_us * 1e-6),
+                                            "peak": peak_pairs, "unit": "descriptor pairs/s", "frac": pairs / (k_us * 1e-6) / peak_pairs,
+                                            "avg_launch_us": k_us, "valu_instructions_per_pair": 20}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import c_oracle as co
+            t1 = time.perf_counter()
+            wi, wd = co.match_knn(des0, des1, 2)
+            w0, w1 = co.select_matches(kp0, kp1, wi, wd)
+            out["aux_matching"]["cpu_port_us_per_step"] = (time.perf_counter() - t1) * 1e6
+            k = int(mn.item())
+            out["aux_matching"]["matches_equal_cpu"] = bool(k == len(w0) and np.array_equal(mm0[:k].cpu().numpy(), w0)
+                                                            and np.array_equal(mm1[:k].cpu().numpy(), w1))
 
     # ---- CPU baseline: the C restatement on this host (rank 0, single GPU runs only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -25,10 +25,10 @@ __device__ __forceinline__ void top2_insert(uint32_t key, uint32_t& k1, uint32_t
 // slice of the train descriptors (blockIdx.y); each wave scans a quarter of the slice.  A train descriptor is
 // wave-uniform, so it arrives through scalar loads and is an SGPR operand of the XORs: 8 v_xor + 8 v_bcnt
 // (accumulating) + 3 integer ops per (query, train) pair, no LDS traffic in the loop.
-// part[(q * gridDim.y + slice) * 2 + {0,1}] = the slice's two smallest keys of query q.
+// part[slice * n0 + q] = the slice's two smallest keys of query q (slice-major: both kernels touch it coalesced).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_match_knn2(const uint32_t* __restrict__ des0, const uint32_t* __restrict__ des1,
-                                                    int n0, int n1, int per_slice, uint32_t* __restrict__ part) {
+                                                    int n0, int n1, int per_slice, uint2* __restrict__ part) {
     __shared__ uint32_t s_k[4][64][2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform, so the train loop runs on the scalar unit
@@ -64,9 +64,7 @@ __global__ __launch_bounds__(256) void k_match_knn2(const uint32_t* __restrict__
             top2_insert(s_k[w][lane][0], k1, k2);
             top2_insert(s_k[w][lane][1], k1, k2);
         }
-        uint32_t* o = part + ((size_t)q * gridDim.y + blockIdx.y) * 2;
-        o[0] = k1;
-        o[1] = k2;
+        part[(size_t)blockIdx.y * n0 + q] = make_uint2(k1, k2);
     }
 }
 
@@ -76,7 +74,7 @@ __global__ __launch_bounds__(256) void k_match_knn2(const uint32_t* __restrict__
 // One workgroup of 1024 threads: an ordered compaction needs a running prefix over the queries.
 // index/distance (n0 x 2, may be NULL): -1 where fewer than two train descriptors exist.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_match_finish(const uint32_t* __restrict__ part, int slices, int n0,
+__global__ __launch_bounds__(1024) void k_match_finish(const uint2* __restrict__ part, int slices, int n0,
                                                        const double2* __restrict__ pts0, const double2* __restrict__ pts1,
                                                        int32_t* __restrict__ index, int32_t* __restrict__ distance,
                                                        double2* __restrict__ m0, double2* __restrict__ m1,
@@ -90,8 +88,12 @@ __global__ __launch_bounds__(1024) void k_match_finish(const uint32_t* __restric
         const int q = q0 + tid;
         uint32_t k1 = SLAM_MATCH_EMPTY, k2 = SLAM_MATCH_EMPTY;
         if (q < n0) {
-            const uint32_t* p = part + (size_t)q * slices * 2;
-            for (int s = 0; s < 2 * slices; ++s) top2_insert(p[s], k1, k2);
+#pragma unroll 4
+            for (int s = 0; s < slices; ++s) {
+                const uint2 k = part[(size_t)s * n0 + q];
+                top2_insert(k.x, k1, k2);
+                top2_insert(k.y, k1, k2);
+            }
         }
         const int i1 = k1 == SLAM_MATCH_EMPTY ? -1 : (int)(k1 & (SLAM_MATCH_MAX_TRAIN - 1));
         const int d1 = k1 == SLAM_MATCH_EMPTY ? -1 : (int)(k1 >> SLAM_MATCH_INDEX_BITS);

@@ -34,6 +34,111 @@ __device__ __forceinline__ double det3x3(const double (&m)[9]) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
 
+// From the least right singular vector of the design matrix to the hypothesis block   (reference:
+// src/triangulation.py:113-132, src/util.py:18-37,60-66)
+__device__ inline void resect_finish(double (&cam)[12], const double* __restrict__ tw, double* __restrict__ hp) {
+    // :115  sign so that det of the left 3x3 block is positive
+    const double m3[9] = {cam[0], cam[1], cam[2], cam[4], cam[5], cam[6], cam[8], cam[9], cam[10]};
+    const double d = det3x3(m3);
+    const double sg = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cam[i] *= sg;
+    // :117-118  the null vector of the 3x4 matrix by cofactors (only its ratios are used)
+    double c4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double s[9];
+        int cc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j == k) continue;
+            s[cc] = cam[j];
+            s[3 + cc] = cam[4 + j];
+            s[6 + cc] = cam[8 + j];
+            ++cc;
+        }
+        c4[k] = ((k & 1) ? -1.0 : 1.0) * det3x3(s);
+    }
+    const double centre[3] = {c4[0] / c4[3], c4[1] / c4[3], c4[2] / c4[3]};
+    // :120  rq_decomposition (src/util.py:60-66): J m = q' r' ; r = J r'^T J ; q = J q'^T.  Gram-Schmidt with one
+    // re-orthogonalisation; whatever signs a QR routine picks for r' cancel in :122-124.
+    double Mp[9], Q[9], Rp[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Mp[3 * i + j] = sg * m3[3 * (2 - i) + j]; Rp[3 * i + j] = 0.0; Q[3 * i + j] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double v[3] = {Mp[j], Mp[3 + j], Mp[6 + j]};
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                const double dot = Q[k] * v[0] + Q[3 + k] * v[1] + Q[6 + k] * v[2];
+                Rp[3 * k + j] += dot;
+                v[0] -= dot * Q[k];
+                v[1] -= dot * Q[3 + k];
+                v[2] -= dot * Q[6 + k];
+            }
+        const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        Rp[3 * j + j] = nrm;
+        Q[j] = v[0] / nrm;
+        Q[3 + j] = v[1] / nrm;
+        Q[6 + j] = v[2] / nrm;
+    }
+    double r[9], q[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            r[3 * i + j] = Rp[3 * (2 - j) + (2 - i)];
+            q[3 * i + j] = Q[3 * j + (2 - i)];
+        }
+    double dg[3], Kc[9], Rm[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dg[i] = r[4 * i] > 0.0 ? 1.0 : (r[4 * i] < 0.0 ? -1.0 : 0.0);  // :122
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Kc[3 * i + j] = r[3 * i + j] * dg[j];  // :123
+            Rm[3 * i + j] = dg[i] * q[3 * i + j];  // :124
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = -1.0 * (Rm[3 * i] * centre[0] + Rm[3 * i + 1] * centre[1] + Rm[3 * i + 2] * centre[2]);  // :125
+
+    double pose[12];  // first three rows of [[R^T, -R^T t]]   (src/util.py:30-37)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pose[4 * i + j] = Rm[3 * j + i];
+            s += Rm[3 * j + i] * t[j];
+        }
+        pose[4 * i + 3] = -s;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) hp[HP_POSE + i] = pose[i];
+    hp[HP_POSE + 12] = 0.0; hp[HP_POSE + 13] = 0.0; hp[HP_POSE + 14] = 0.0; hp[HP_POSE + 15] = 1.0;
+    const double* __restrict__ K = tw + TW_K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            hp[HP_P1 + 4 * i + j] = K[3 * i] * pose[j] + K[3 * i + 1] * pose[4 + j] + K[3 * i + 2] * pose[8 + j];
+    // what the scoring loop reads back from the pose: src/util.py:18-27
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        hp[HP_T + i] = -1.0 * (pose[i] * pose[3] + pose[4 + i] * pose[7] + pose[8 + i] * pose[11]);
+        hp[HP_CZ + i] = pose[8 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { hp[HP_EXTRA + i] = Kc[i]; hp[HP_EXTRA + 9 + i] = Rm[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { hp[HP_EXTRA + 18 + i] = t[i]; hp[HP_EXTRA + 21 + i] = centre[i]; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5: resection, one lane per hypothesis   (reference: src/triangulation.py:98-132)
 //   Rows [0,0,0,0,-X,-Y,-Z,-1, vX,vY,vZ,v] and [X,Y,Z,1, 0,0,0,0, -uX,-uY,-uZ,-u] of every chosen match are folded
@@ -133,107 +238,113 @@ __global__ __launch_bounds__(SLAM_RESECT_LANES) void k_resect(const double2* __r
 #undef R_
 #undef V_
 
-    // :115  sign so that det of the left 3x3 block is positive
-    const double m3[9] = {cam[0], cam[1], cam[2], cam[4], cam[5], cam[6], cam[8], cam[9], cam[10]};
-    const double d = det3x3(m3);
-    const double sg = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) cam[i] *= sg;
-    // :117-118  the null vector of the 3x4 matrix by cofactors (only its ratios are used)
-    double c4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double s[9];
-        int cc = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j == k) continue;
-            s[cc] = cam[j];
-            s[3 + cc] = cam[4 + j];
-            s[6 + cc] = cam[8 + j];
-            ++cc;
-        }
-        c4[k] = ((k & 1) ? -1.0 : 1.0) * det3x3(s);
-    }
-    const double centre[3] = {c4[0] / c4[3], c4[1] / c4[3], c4[2] / c4[3]};
-    // :120  rq_decomposition (src/util.py:60-66): J m = q' r' ; r = J r'^T J ; q = J q'^T.  Gram-Schmidt with one
-    // re-orthogonalisation; whatever signs a QR routine picks for r' cancel in :122-124.
-    double Mp[9], Q[9], Rp[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { Mp[3 * i + j] = sg * m3[3 * (2 - i) + j]; Rp[3 * i + j] = 0.0; Q[3 * i + j] = 0.0; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        double v[3] = {Mp[j], Mp[3 + j], Mp[6 + j]};
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-            for (int k = 0; k < j; ++k) {
-                const double dot = Q[k] * v[0] + Q[3 + k] * v[1] + Q[6 + k] * v[2];
-                Rp[3 * k + j] += dot;
-                v[0] -= dot * Q[k];
-                v[1] -= dot * Q[3 + k];
-                v[2] -= dot * Q[6 + k];
-            }
-        const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        Rp[3 * j + j] = nrm;
-        Q[j] = v[0] / nrm;
-        Q[3 + j] = v[1] / nrm;
-        Q[6 + j] = v[2] / nrm;
-    }
-    double r[9], q[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            r[3 * i + j] = Rp[3 * (2 - j) + (2 - i)];
-            q[3 * i + j] = Q[3 * j + (2 - i)];
-        }
-    double dg[3], Kc[9], Rm[9], t[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) dg[i] = r[4 * i] > 0.0 ? 1.0 : (r[4 * i] < 0.0 ? -1.0 : 0.0);  // :122
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Kc[3 * i + j] = r[3 * i + j] * dg[j];  // :123
-            Rm[3 * i + j] = dg[i] * q[3 * i + j];  // :124
-        }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = -1.0 * (Rm[3 * i] * centre[0] + Rm[3 * i + 1] * centre[1] + Rm[3 * i + 2] * centre[2]);  // :125
+    resect_finish(cam, tw, hyp + (size_t)h * HP_LEN);
+}
 
-    double* __restrict__ hp = hyp + (size_t)h * HP_LEN;
-    double pose[12];  // first three rows of [[R^T, -R^T t]]   (src/util.py:30-37)
+// ------------------------------------------------------------------------------------------------
+// K5b: resection of six-point samples, sixteen lanes per hypothesis (four hypotheses per wave).
+//   The 12x12 design matrix needs no triangular factor here: lane c of a group holds column c of the matrix and
+//   column c of V in registers, and the one-sided Jacobi runs in tournament order - in each of the 11 rounds of a
+//   sweep the 12 columns form 6 disjoint pairs that rotate at the same time.  A lane fetches its partner's two
+//   columns with 48 ds_bpermute, both lanes of a pair derive the same angle from the same three sums, and each
+//   keeps its own side of the rotation.  Same thresholds as the one-lane kernel; sweeps end when no pair of the
+//   wave rotates.  Lanes 12..15 of a group idle.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, const double* __restrict__ X3,
+                                                const int32_t* __restrict__ idx, int H, const double* __restrict__ tw,
+                                                double* __restrict__ hyp) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15;                  // column owned by this lane
+    const int base = lane & 48;               // first lane of the group
+    const int h = blockIdx.x * 4 + (lane >> 4);
+    const bool owner = c < 12 && h < H;
+    const int hh = h < H ? h : H - 1;
+    double a[12], v[12];
+    // column c of the design matrix: rows 2p = [0,0,0,0, -Xh, v Xh], rows 2p+1 = [Xh, 0,0,0,0, -u Xh]
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double s = 0.0;
+    for (int p = 0; p < 6; ++p) {
+        const int i = idx[(size_t)hh * 6 + p];
+        const double2 q = uv[i];
+        const int k = c & 3;
+        const double xk = k == 3 ? 1.0 : X3[3 * (size_t)i + k];
+        const int blk = c >> 2;               // 0: first four columns, 1: middle, 2: last (3 for idle lanes)
+        a[2 * p] = blk == 1 ? -xk : (blk == 2 ? q.y * xk : 0.0);
+        a[2 * p + 1] = blk == 0 ? xk : (blk == 2 ? -q.x * xk : 0.0);
+    }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            pose[4 * i + j] = Rm[3 * j + i];
-            s += Rm[3 * j + i] * t[j];
+    for (int i = 0; i < 12; ++i) v[i] = (i == c) ? 1.0 : 0.0;
+    if (c >= 12) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a[i] = 0.0;
+    }
+    // squared Frobenius norm of the group's matrix -> rounding floor
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) n2 = fma(a[i], a[i], n2);
+    double fro2 = n2;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) fro2 += __shfl_xor(fro2, m, 64);
+    const double floor2 = fro2 * 1e-32;
+
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+#pragma unroll 1
+        for (int r = 0; r < 11; ++r) {
+            // circle method: column 11 stays, the others meet the column at the mirrored position around r
+            int partner;
+            if (c >= 12) partner = c;
+            else if (c == 11) partner = r;
+            else if (c == r) partner = 11;
+            else { partner = 2 * r - c; partner += partner < 0 ? 11 : 0; partner -= partner >= 11 ? 11 : 0; }
+            const int src = base + partner;
+            double pa[12], pv[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                pa[i] = __shfl(a[i], src, 64);
+                pv[i] = __shfl(v[i], src, 64);
+            }
+            // the pair in (lower column, higher column) order, the same on both of its lanes
+            const bool low = c < partner;
+            double sp = 0.0, sq = 0.0, spq = 0.0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const double x = low ? a[i] : pa[i], y = low ? pa[i] : a[i];
+                sp = fma(x, x, sp);
+                sq = fma(y, y, sq);
+                spq = fma(x, y, spq);
+            }
+            const bool go = c != partner && sp > floor2 && sq > floor2 && spq * spq > 1e-30 * (sp * sq);
+            double cs, sn;
+            jacobi_angle(sp, sq, spq, cs, sn);
+            cs = go ? cs : 1.0;
+            sn = go ? sn : 0.0;
+            rotated |= go;
+            // lower column: cs x - sn y ; higher column: sn x + cs y
+            const double mine = cs, other = low ? -sn : sn;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                a[i] = fma(mine, a[i], other * pa[i]);
+                v[i] = fma(mine, v[i], other * pv[i]);
+            }
         }
-        pose[4 * i + 3] = -s;
+        if (!__any(rotated)) break;
     }
+    // the column with the smallest norm; ties to the lower column
+    n2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) hp[HP_POSE + i] = pose[i];
-    hp[HP_POSE + 12] = 0.0; hp[HP_POSE + 13] = 0.0; hp[HP_POSE + 14] = 0.0; hp[HP_POSE + 15] = 1.0;
-    const double* __restrict__ K = tw + TW_K;
+    for (int i = 0; i < 12; ++i) n2 = fma(a[i], a[i], n2);
+    if (c >= 12) n2 = 1e300;
+    double best = n2;
+    int who = c;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            hp[HP_P1 + 4 * i + j] = K[3 * i] * pose[j] + K[3 * i + 1] * pose[4 + j] + K[3 * i + 2] * pose[8 + j];
-    // what the scoring loop reads back from the pose: src/util.py:18-27
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        hp[HP_T + i] = -1.0 * (pose[i] * pose[3] + pose[4 + i] * pose[7] + pose[8 + i] * pose[11]);
-        hp[HP_CZ + i] = pose[8 + i];
+    for (int m = 1; m < 16; m <<= 1) {
+        const double ob = __shfl_xor(best, m, 64);
+        const int ow = __shfl_xor(who, m, 64);
+        const bool take = ob < best || (ob == best && ow < who);
+        best = take ? ob : best;
+        who = take ? ow : who;
     }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { hp[HP_EXTRA + i] = Kc[i]; hp[HP_EXTRA + 9 + i] = Rm[i]; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { hp[HP_EXTRA + 18 + i] = t[i]; hp[HP_EXTRA + 21 + i] = centre[i]; }
+    if (owner && who == c) resect_finish(v, tw, hyp + (size_t)h * HP_LEN);  // vh[-1].reshape(3,4)   :113-114
 }
 
 // fills the call's work block: K prev_pose[:3], prev_pose[:3], K.  kp.A = K, kp.B unused; prev (12) by value too.

@@ -772,9 +772,8 @@ static int track_enqueue(slam_ctx* ctx, const double* previous_pose, const doubl
     SLAM_TRY(slam_launch(ctx, -1, k_sample, dim3((H + 63) / 64), dim3(64), 0, (int)SLAM_SAMPLER_CPYTHON,
                          (uint64_t)SLAM_SEED_BASE, (int64_t)0, H, M, 6, (const uint32_t*)ctx->raw.p, ctx->raw_it0,
                          (int32_t*)ctx->idx.p, (int32_t*)ctx->flags.p));
-    SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect, dim3((H + SLAM_RESECT_LANES - 1) / SLAM_RESECT_LANES),
-                         dim3(SLAM_RESECT_LANES), 0, (const double2*)d_b, d_X3, M, (const int32_t*)ctx->idx.p, H,
-                         (const double*)tw, hyp));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect6, dim3((H + 3) / 4), dim3(64), 0, (const double2*)d_b, d_X3,
+                         (const int32_t*)ctx->idx.p, H, (const double*)tw, hyp));
     SLAM_TRY(slam_launch(ctx, SLAM_K_TRACK_SCORE, k_track_score, dim3(H), dim3(256), 0, (const double*)tw,
                          (const double*)hyp, (const double2*)d_a, (const double2*)d_b, d_X3, M,
                          (int32_t*)ctx->counts.p, (double*)ctx->errsums.p));

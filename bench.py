@@ -13,6 +13,7 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
                 kernel is float64 FMA work on 416 KB of L2-resident data), counting the scoring flops only; durations from HIP events attached to each
                 launch on the library's stream during a second timed pass of K steps
   cpu_baseline  the C restatement in oracle/ timed on this host's cores (rank 0, N=1 only)
+  aux_batched_pairs  100 frame pairs (the batched-sequence configuration) through slam_init_pairs
   aux_tracking  the tracking step (pose from 2D-3D matches + its 100-hypothesis loop), one call per step
   aux_matching  Hamming 2-NN descriptor matching with ratio test, 4096 x 4096 descriptors
   aux           bulk triangulation + cheirality throughput (4 candidates per point) with its own roofline
@@ -310,6 +311,35 @@ def main():
                                    "hbm_GBps_algorithmic": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9,
                                    "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM}}
         del p0, p1, d_X
+
+    # ---- aux: batched sequence, 100 frame pairs sharded over the ranks, whole initialisation per pair (host buffers)
+    if not args.no_aux:
+        from slam_amd import pipeline
+        NP_, NB, IB = 100, 2000, 1000
+        mine = [i for i in range(NP_) if i % world == rank]
+        pdata = [synth.make_pair(NB, 0.3, seed=400 + i) for i in mine]
+        plist = [(d["pts0"], d["pts1"]) for d in pdata]
+        Kb = pdata[0]["K"]
+        pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)           # warm-up (buffers, sampler table)
+        barrier()
+        t0 = time.perf_counter()
+        res = pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)
+        barrier()
+        bdt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        one = [pipeline.initialise_pair(a_, b_, Kb, iterations=IB, ctx=ctx) for a_, b_ in plist[:10]]
+        sdt = (time.perf_counter() - t0) / 10
+        if use_dist:
+            t = torch.tensor([bdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bdt = float(t.item())
+        out["aux_batched_pairs"] = {"workload": f"{NP_} frame pairs (N={NB} matches, 30% outliers, {IB} hypotheses, KITTI intrinsics) "
+                                                f"split over {world} GPU(s); whole initialisation per pair (normalise, RANSAC, "
+                                                "F->E, 4-candidate triangulation, selection), host buffers in and out, one call per rank",
+                                    "scaling": "strong", "ms_per_batch": bdt * 1e3, "pairs_per_sec": NP_ / bdt,
+                                    "hypotheses_per_sec": NP_ * IB / bdt, "us_per_pair_single_calls": sdt * 1e6,
+                                    "same_as_single_calls": bool(all(np.array_equal(x["X"], y["X"]) for x, y in zip(res, one))),
+                                    "mean_inliers": float(np.mean([r["record"][_lib.REC_COUNT] for r in res]))}
 
     # ---- aux: tracking step (pose from 2D-3D matches, 100 hypotheses), inputs resident in HBM
     if not args.no_aux:

@@ -131,6 +131,15 @@ int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* pts1, int N,
                    double* F, double* E, double* pose, double* X, uint8_t* good, double* record,
                    int32_t* counts4, int32_t* winner);
 
+/* A batch of independent pairs in one call: one upload, one download, one synchronisation; the pairs' kernels are
+ * spread over the context's internal streams.  pts0/pts1: the pairs' matches concatenated, (offsets[P], 2);
+ * pair p owns rows offsets[p] .. offsets[p+1]-1 (at least 8).  Outputs as slam_init_pair, per pair: F, E (P x 9),
+ * pose (P x 16), record (P x 12), counts4 (P x 4), winner (P); per match: X (offsets[P] x 3), good (offsets[P]).
+ * Any output may be NULL.  Results are bit-identical to P calls of slam_init_pair. */
+int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* pts1, const int64_t* offsets, int P,
+                    const double* K, int iterations, double* F, double* E, double* pose, double* X, uint8_t* good,
+                    double* record, int32_t* counts4, int32_t* winner);
+
 /* ---- tracking step: src/triangulation.py:78-182 ------------------------------------------------- */
 /* number of hypotheses the tracking loop runs: min(iterations, C(M, 6))   (src/triangulation.py:145-146) */
 int64_t slam_num_tracking_hypotheses(int64_t n_known, int64_t iterations);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "slam_pose_candidates_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "slam_pose_select_dev": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "slam_init_pair": (_int, [_vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slam_init_pairs": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "slam_num_tracking_hypotheses": (_i64, [_i64, _i64]),
     "slam_pose_from_points": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
     "slam_track_pose": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),

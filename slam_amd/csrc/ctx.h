@@ -53,6 +53,8 @@ struct slam_ctx {
     slam_buf small;     // small matrices: candidates, poses, T, E ...
     slam_buf flags;     // int32[4] error flags written by kernels
     slam_buf track;     // tracking step: work block + per-hypothesis blocks
+    slam_buf batch;     // slam_init_pairs: all pairs' points, planes and per-pair blocks
+    hipEvent_t lane_event[SLAM_LANES + 1] = {nullptr, nullptr, nullptr, nullptr};  // created on first use
     slam_buf match;     // descriptor matching: per-slice candidate keys, staged descriptors and points
     uint64_t raw_seed = 0;
     int64_t raw_it0 = 0, raw_n = 0;

@@ -83,7 +83,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)slam_sync_all(ctx);
     slam_buf* bufs[] = {&ctx->pts, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
-                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track, &ctx->match};
+                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track, &ctx->match, &ctx->batch};
     for (slam_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int l = 0; l < SLAM_LANES; ++l) {
@@ -92,6 +92,8 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
         if (ctx->lane_errsums[l].p) (void)hipFree(ctx->lane_errsums[l].p);
         if (l > 0 && ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
     }
+    for (hipEvent_t ev : ctx->lane_event)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->prof.created)
@@ -277,6 +279,8 @@ extern "C" int64_t slam_num_hypotheses(int64_t n_points, int64_t iterations) {
     }
     return (int64_t)c;
 }
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int check_flags(slam_ctx* ctx) {
     SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->flags.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -709,6 +713,115 @@ extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* p
     return SLAM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// a batch of pairs
+// ------------------------------------------------------------------------------------------------
+namespace {
+enum { PB_PW = 0, PB_COUNTS = 256, PB_POSE = 260, PB_WIN = 276, PB_REC = 280, PB_LEN = 320 };  // per-pair block, f64 words
+static_assert(PW_LEN <= PB_COUNTS, "the pose work block must fit its slot");
+}  // namespace
+
+extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* pts1, const int64_t* offsets, int P,
+                               const double* K, int iterations, double* F, double* E, double* pose, double* X,
+                               uint8_t* good, double* record, int32_t* counts4, int32_t* winner) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, pts0 && pts1 && offsets && K, "NULL pointer");
+    SLAM_REQUIRE(ctx, P >= 1, "no pairs");
+    SLAM_REQUIRE(ctx, iterations >= 1, "iterations < 1");
+    SLAM_REQUIRE(ctx, offsets[0] == 0, "offsets must start at 0");
+    int maxH = 0;
+    for (int p = 0; p < P; ++p) {
+        const int64_t n = offsets[p + 1] - offsets[p];
+        SLAM_REQUIRE(ctx, n >= 8 && n <= INT32_MAX, "a pair has fewer than 8 matches (or too many)");
+        maxH = std::max(maxH, (int)slam_num_hypotheses(n, iterations));
+    }
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t total = offsets[P];
+    const bool lanes = ctx->stream == ctx->own_stream;  // a caller-supplied stream keeps everything in order on it
+    const int L = lanes ? SLAM_LANES : 1;
+    // every allocation first: growing a buffer synchronises the context
+    const size_t b_pts = align256((size_t)total * 16), b_x = align256((size_t)total * 24), b_m = align256((size_t)total);
+    const size_t b_blk = (size_t)P * PB_LEN * sizeof(double);
+    SLAM_TRY(slam_reserve(ctx, ctx->batch, 4 * b_pts + 5 * b_x + b_m + b_blk));
+    for (int l = 0; l < L; ++l) {
+        SLAM_TRY(slam_reserve(ctx, ctx->lane_F[l], (size_t)maxH * 9 * sizeof(double)));
+        SLAM_TRY(slam_reserve(ctx, ctx->lane_counts[l], (size_t)maxH * sizeof(int32_t)));
+        SLAM_TRY(slam_reserve(ctx, ctx->lane_errsums[l], (size_t)maxH * sizeof(double)));
+    }
+    SLAM_TRY(slam_fill_raw_table(ctx, SLAM_SEED_BASE, 0, maxH));
+    for (int l = 0; l <= SLAM_LANES; ++l)
+        if (!ctx->lane_event[l]) SLAM_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_event[l], hipEventDisableTiming));
+    char* base = (char*)ctx->batch.p;
+    double *r0 = (double*)base, *r1 = (double*)(base + b_pts), *n0 = (double*)(base + 2 * b_pts), *n1 = (double*)(base + 3 * b_pts);
+    double* X4 = (double*)(base + 4 * b_pts);
+    double* dX = (double*)(base + 4 * b_pts + 4 * b_x);
+    uint8_t* dmask = (uint8_t*)(base + 4 * b_pts + 5 * b_x);
+    double* blocks = (double*)(base + 4 * b_pts + 5 * b_x + b_m);
+    SLAM_HIP(ctx, hipMemcpyAsync(r0, pts0, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(r1, pts1, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (L > 1) {
+        SLAM_HIP(ctx, hipEventRecord(ctx->lane_event[SLAM_LANES], ctx->stream));
+        for (int l = 1; l < L; ++l) SLAM_HIP(ctx, hipStreamWaitEvent(ctx->lane_stream[l], ctx->lane_event[SLAM_LANES], 0));
+    }
+    Mat3x2 kk;
+    memcpy(kk.A, K, sizeof kk.A);
+    memset(kk.B, 0, sizeof kk.B);
+    int rc = SLAM_OK;
+    for (int p = 0; p < P && rc == SLAM_OK; ++p) {
+        const int l = p % L;
+        const int64_t off = offsets[p];
+        const int N = (int)(offsets[p + 1] - off);
+        const int H = (int)slam_num_hypotheses(N, iterations);
+        double* blk = blocks + (size_t)p * PB_LEN;
+        double* pw = blk + PB_PW;
+        unsigned long long* d_counts4 = (unsigned long long*)(blk + PB_COUNTS);
+        const double2 *a0 = (const double2*)(r0 + 2 * off), *a1 = (const double2*)(r1 + 2 * off);
+        double *m0 = n0 + 2 * off, *m1 = n1 + 2 * off;
+        double* x4 = X4 + 4 * 3 * off;
+        ctx->cur = lanes ? ctx->lane_stream[l] : ctx->stream;
+        auto go = [&]() -> int {
+            SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, a0, N, (double2*)m0, pw + PW_T0));
+            SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, a1, N, (double2*)m1, pw + PW_T1));
+            SLAM_TRY(ransac_enqueue(ctx, m0, m1, N, nullptr, SLAM_SAMPLER_CPYTHON, SLAM_SEED_BASE, 0, H,
+                                    SLAM_DEFAULT_THRESHOLD, blk + PB_REC, nullptr, (int32_t*)ctx->lane_counts[l].p,
+                                    (double*)ctx->lane_errsums[l].p, (double*)ctx->lane_F[l].p));
+            SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1), dim3(64), 0, kk, (const double*)(blk + PB_REC), pw, d_counts4));
+            SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                                 (const double*)pw, a0, a1, (int64_t)N, x4, d_counts4));
+            SLAM_TRY(slam_launch(ctx, -1, k_pose_select, dim3(1), dim3(64), 0, (const double*)pw,
+                                 (const unsigned long long*)d_counts4, blk + PB_POSE, (int32_t*)(blk + PB_WIN)));
+            const unsigned eb = (unsigned)std::min<int64_t>(((int64_t)N * 3 + 255) / 256, 4096);
+            SLAM_TRY(slam_launch(ctx, -1, k_emit_points, dim3(eb), dim3(256), 0, (const double*)x4,
+                                 (const int32_t*)(blk + PB_WIN), (int64_t)N, dX + 3 * off, dmask + off));
+            return SLAM_OK;
+        };
+        rc = go();
+    }
+    ctx->cur = ctx->stream;
+    SLAM_TRY(rc);
+    if (L > 1)
+        for (int l = 1; l < L; ++l) {
+            SLAM_HIP(ctx, hipEventRecord(ctx->lane_event[l], ctx->lane_stream[l]));
+            SLAM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_event[l], 0));
+        }
+    std::vector<double> hb((size_t)P * PB_LEN);
+    SLAM_HIP(ctx, hipMemcpyAsync(hb.data(), blocks, b_blk, hipMemcpyDeviceToHost, ctx->stream));
+    if (X) SLAM_HIP(ctx, hipMemcpyAsync(X, dX, (size_t)total * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (good) SLAM_HIP(ctx, hipMemcpyAsync(good, dmask, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_TRY(check_flags(ctx));
+    for (int p = 0; p < P; ++p) {
+        const double* blk = hb.data() + (size_t)p * PB_LEN;
+        if (E) memcpy(E + 9 * (size_t)p, blk + PB_PW + PW_E, 9 * sizeof(double));
+        if (F) memcpy(F + 9 * (size_t)p, blk + PB_PW + PW_F, 9 * sizeof(double));
+        if (pose) memcpy(pose + 16 * (size_t)p, blk + PB_POSE, 16 * sizeof(double));
+        if (record) memcpy(record + SLAM_REC_LEN * (size_t)p, blk + PB_REC, SLAM_REC_LEN * sizeof(double));
+        const int64_t* c = (const int64_t*)(blk + PB_COUNTS);
+        if (counts4) for (int i = 0; i < 4; ++i) counts4[4 * (size_t)p + i] = (int32_t)c[i];
+        if (winner) winner[p] = *(const int32_t*)(blk + PB_WIN);
+    }
+    return SLAM_OK;
+}
+
 // ================================================================================================
 // tracking step
 // ================================================================================================
@@ -854,7 +967,6 @@ extern "C" int slam_track_pose(slam_ctx* ctx, const double* previous_pose, const
 // ================================================================================================
 // descriptor matching
 // ================================================================================================
-static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // number of train slices: about 1024 workgroups in all (measured best at 4096 x 4096), slices of at least 64 descriptors
 static int match_slices(int n0, int n1) {

@@ -49,6 +49,40 @@ def initialise_pair(img0_points, img1_points, intrinsic_camera_matrix, iteration
     return dict(F=F, E=E, pose=pose, X=X, mask=good.astype(bool), record=record, counts=counts4, winner=int(winner[0]))
 
 
+def initialise_pairs(pairs, intrinsic_camera_matrix, iterations=1000, ctx=None):
+    """initialise_pair for a batch of independent pairs in one library call (one upload, one download; the pairs'
+    kernels overlap on the context's internal streams).  pairs: sequence of (img0_points, img1_points).
+    Returns a list of the dicts initialise_pair returns, bit-identical to calling it pair by pair."""
+    K = f64(intrinsic_camera_matrix)
+    a = [f64(np.asarray(p0)) for p0, _ in pairs]
+    b = [f64(np.asarray(p1)) for _, p1 in pairs]
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and x.ndim == 2 and x.shape[1] == 2
+        assert len(x) >= 8
+    P = len(a)
+    if P == 0:
+        return []
+    offsets = np.zeros(P + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(x) for x in a])
+    total = int(offsets[-1])
+    p0, p1 = np.concatenate(a), np.concatenate(b)
+    F, E, pose = np.empty((P, 3, 3)), np.empty((P, 3, 3)), np.empty((P, 4, 4))
+    X = np.empty((total, 3))
+    good = np.empty(total, dtype=np.uint8)
+    record = np.empty((P, REC_LEN))
+    counts4 = np.empty((P, 4), dtype=np.int32)
+    winner = np.empty(P, dtype=np.int32)
+    ctx = ctx or _lib.default_context()
+    ctx.check(ctx.lib.slam_init_pairs(ctx.handle, ptr(p0), ptr(p1), ptr(offsets), P, ptr(K), int(iterations), ptr(F), ptr(E),
+                                      ptr(pose), ptr(X), ptr(good), ptr(record), ptr(counts4), ptr(winner)))
+    out = []
+    for i in range(P):
+        lo, hi = int(offsets[i]), int(offsets[i + 1])
+        out.append(dict(F=F[i], E=E[i], pose=pose[i], X=X[lo:hi], mask=good[lo:hi].astype(bool), record=record[i],
+                        counts=counts4[i], winner=int(winner[i])))
+    return out
+
+
 def find_pose_and_triangulated_points(img0_points, img1_points, intrinsic_camera_matrix, iterations=1000):
     """The reference's return tuple (custom_slam.py:105-115), starting from matches instead of images."""
     r = initialise_pair(img0_points, img1_points, intrinsic_camera_matrix, iterations)

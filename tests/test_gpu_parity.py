@@ -500,3 +500,42 @@ def test_config4_batch_of_pairs(ctx):
         assert np.allclose(r["pose"], pose, atol=1e-7)
         assert point_err(r["X"], X) < X_TOL
         assert np.array_equal(r["mask"], X[:, 2] > 0)
+
+
+def test_batched_pairs_equal_single_pairs(ctx):
+    """slam_init_pairs on a ragged batch (sizes 8 .. 5000, including the shapes that take the three scoring
+    configurations) returns bit for bit what slam_init_pair returns pair by pair."""
+    sizes = [2048, 8, 100, 4096, 513, 5000, 2048, 12, 300, 1000, 2048, 64, 2048]
+    data = [synth.make_pair(n, 0.3, seed=300 + i) for i, n in enumerate(sizes)]
+    K = data[0]["K"]
+    batch = pipeline.initialise_pairs([(d["pts0"], d["pts1"]) for d in data], K, iterations=500, ctx=ctx)
+    assert len(batch) == len(sizes)
+    for d, b in zip(data, batch):
+        r = pipeline.initialise_pair(d["pts0"], d["pts1"], K, iterations=500, ctx=ctx)
+        for key in ("F", "E", "pose", "X", "mask", "record", "counts"):
+            assert np.array_equal(np.asarray(b[key]), np.asarray(r[key]), equal_nan=True), (len(d["pts0"]), key)
+        assert b["winner"] == r["winner"]
+
+
+def test_config4_hundred_pairs_in_one_call(ctx):
+    """Configuration 4 as one batch: 100 frame pairs with KITTI intrinsics, 1000 iterations each; a sample of the
+    pairs is checked against the C restatement, all of them for plausibility."""
+    data = [synth.make_pair(2000, 0.3, seed=400 + i) for i in range(100)]
+    K = data[0]["K"]
+    batch = pipeline.initialise_pairs([(d["pts0"], d["pts1"]) for d in data], K, iterations=1000, ctx=ctx)
+    for i, (d, b) in enumerate(zip(data, batch)):
+        assert int(b["record"][_lib.REC_COUNT]) >= 0.6 * 2000, i          # 70 % of the matches are true
+        assert b["mask"].sum() >= 0.6 * 2000
+    for i in (0, 37, 99):
+        d, b = data[i], batch[i]
+        n0, T0 = co.normalize_points(d["pts0"])
+        n1, T1 = co.normalize_points(d["pts1"])
+        o = co.ransac(n0, n1, co.sample(2000, 1000), threads=8)
+        assert int(b["record"][_lib.REC_INDEX]) == o["best_index"]
+        assert int(b["record"][_lib.REC_COUNT]) == o["best_count"]
+        F = T1.T @ o["best_F"] @ T0
+        assert rel_err(fix_sign_scale(b["F"]), fix_sign_scale(F)) < F_TOL
+        E = so.fundamental_to_essential(F, K)
+        pose, X, counts, w = co.pose_from_E(E, K, d["pts0"], d["pts1"], threads=8)
+        assert np.allclose(b["pose"], pose, atol=1e-7)
+        assert point_err(b["X"], X) < X_TOL

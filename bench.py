@@ -197,6 +197,23 @@ def main():
                               "hypotheses_per_sec": HL / bdt, "residual_evals_per_sec": HL * N_MATCHES / bdt,
                               "roofline": {"kernel": "k_score", "bound": "valu_fp64", "achieved": tfl, "peak": PEAK_FP64_VALU,
                                            "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_VALU, "avg_launch_us": sc_us}}
+        # the same 65536 hypotheses scored with the Sampson distance (optional mode, not the reference's residual)
+        ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_SAMPSON))
+        big_step()
+        barrier()
+        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+        ctx.check(lib.slam_profile_reset(ctx.handle))
+        t0 = time.perf_counter()
+        for _ in range(10):
+            big_step()
+        barrier()
+        sdt_ = (time.perf_counter() - t0) / 10
+        ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms), C.byref(n)))
+        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+        ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_ALGEBRAIC))
+        out["aux_large_h"]["sampson_mode"] = {"sampson_evals_per_sec": HL * N_MATCHES / sdt_,
+                                              "k_score_us": ms.value / max(n.value, 1) * 1e3,
+                                              "k_score_sampson_evals_per_sec": HL * N_MATCHES / (ms.value / max(n.value, 1) * 1e-3)}
         # host-buffer entry point (what the Python drop-in pays): upload, run, download, synchronise
         from slam_amd import epipolar
         epipolar.ransac_detailed(n0, n1, N_HYP, ctx=ctx)

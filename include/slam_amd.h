@@ -63,6 +63,14 @@ int slam_set_stream(slam_ctx* ctx, void* hip_stream);
  * independent of each other, use distinct output buffers, and their outputs are ready only after slam_synchronize().
  * Ignored while a caller-supplied stream is set.  No counterpart in the reference (it is single-threaded). */
 int slam_set_concurrency(slam_ctx* ctx, int lanes);
+/* Residual the RANSAC entry points score with (slam_ransac_f, slam_ransac_f_dev, slam_ransac_f_adaptive; the pair
+ * pipelines always use the reference's).  SLAM_SCORE_ALGEBRAIC (default) is the reference's squared algebraic
+ * residual ((x1^T F) x0)^2 (src/epipolar.py:73).  SLAM_SCORE_SAMPSON divides it by
+ * (F^T x1)_0^2 + (F^T x1)_1^2 + (F x0)_0^2 + (F x0)_1^2, the first-order geometric distance; `threshold` then applies
+ * to that quantity.  No counterpart in the reference. */
+#define SLAM_SCORE_ALGEBRAIC 0
+#define SLAM_SCORE_SAMPSON 1
+int slam_set_scoring(slam_ctx* ctx, int mode);
 /* waits for everything the context has queued, on every internal stream */
 int slam_synchronize(slam_ctx* ctx);
 
@@ -92,6 +100,15 @@ int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, int N, cons
 int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                       int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
                       uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all);
+/* Adaptive termination (the standard RANSAC stopping rule; no counterpart in the reference, which always runs every
+ * iteration).  Iterations 0, 1, 2, ... are scored in chunks of `chunk`; after each chunk the number of iterations
+ * needed to have drawn, with probability `confidence`, at least one sample of 8 inliers is re-estimated from the best
+ * inlier ratio w so far, ceil(log(1 - confidence) / log(1 - w^8)), and the loop stops once that many (or
+ * max_iterations) have been scored.  The outcome is exactly the fixed-length outcome of slam_ransac_f for
+ * *iterations_run iterations: chunks are contiguous ranges merged by the reference's rule.  Host pointers. */
+int slam_ransac_f_adaptive(slam_ctx* ctx, const double* p0, const double* p1, int N, int sampler, uint64_t seed,
+                           int64_t max_iterations, int chunk, double confidence, double threshold, double* record,
+                           uint8_t* mask, int64_t* iterations_run);
 /* Merge per-rank winner records (host memory, n_records * SLAM_REC_LEN) by the same rule; used after the
  * all-gather of a hypothesis-sharded run.  Writes the winning record to out and returns its position. */
 int slam_merge_records(const double* records, int n_records, double* out);

@@ -19,6 +19,7 @@ REC_COUNT, REC_ERRSUM, REC_INDEX, REC_F, REC_LEN = 0, 1, 2, 3, 12
 SAMPLER_CPYTHON, SAMPLER_COUNTER = 0, 1
 SEED_BASE = 0x1337BEEF
 DEFAULT_THRESHOLD = 0.005
+SCORE_ALGEBRAIC, SCORE_SAMPSON = 0, 1
 K_SOLVE, K_SCORE, K_SELECT, K_TRIANGULATE, K_RESECT, K_TRACK_SCORE, K_MATCH = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/slam_amd.h declares, with its ctypes signature
@@ -29,12 +30,14 @@ SIGNATURES = {
     "slam_last_error": (C.c_char_p, [_vp]),
     "slam_set_stream": (_int, [_vp, _vp]),
     "slam_set_concurrency": (_int, [_vp, _int]),
+    "slam_set_scoring": (_int, [_vp, _int]),
     "slam_synchronize": (_int, [_vp]),
     "slam_num_hypotheses": (_i64, [_i64, _i64]),
     "slam_sample_indices": (_int, [_vp, _int, _u64, _i64, _int, _int, _int, _vp]),
     "slam_eightpoint": (_int, [_vp, _vp, _vp, _int, _vp]),
     "slam_ransac_f": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
     "slam_ransac_f_dev": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "slam_ransac_f_adaptive": (_int, [_vp, _vp, _vp, _int, _int, _u64, _i64, _int, _f64, _f64, _vp, _vp, _vp]),
     "slam_merge_records": (_int, [_vp, _int, _vp]),
     "slam_normalize_points": (_int, [_vp, _vp, _int, _vp, _vp]),
     "slam_fundamental_to_essential": (_int, [_vp, _vp, _vp, _vp]),

@@ -36,6 +36,7 @@ struct slam_ctx {
     hipStream_t lane_stream[SLAM_LANES] = {nullptr, nullptr, nullptr};
     unsigned next_lane = 0;
     int lanes_in_use = 1;               // slam_set_concurrency
+    bool sampson = false;               // slam_set_scoring
     char err[512] = {0};
 
     // device scratch (grown on demand, never shrunk)

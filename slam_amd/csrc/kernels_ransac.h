@@ -373,7 +373,17 @@ struct MatchChunk {  // PPL matches per lane of a chunk of 64*WAVES*PPL, plus wh
     }
 };
 
-template <int HB, int PPL, int WAVES>
+// Sampson distance of one match (optional scoring mode, not the reference's): r^2 / (l0^2 + l1^2 + m0^2 + m1^2) with
+// l = F^T x1 and m = F x0.  The same expression serves the counts, the sums and the winner's mask.
+__device__ __forceinline__ double sampson_error(double r, double l0, double l1, double a0, double a1, double f00,
+                                                double f01, double f02, double f10, double f11, double f12) {
+    const double m0 = fma(f00, a0, fma(f01, a1, f02));
+    const double m1 = fma(f10, a0, fma(f11, a1, f12));
+    const double den = fma(l0, l0, fma(l1, l1, fma(m0, m0, m1 * m1)));
+    return (r * r) * fast_rcp(den);
+}
+
+template <int HB, int PPL, int WAVES, bool SAMPSON>
 __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
                                                  MatchChunk<PPL, WAVES>& m, const double (*s_F)[9], double rcut,
                                                  int h0, int H, int32_t* __restrict__ counts,
@@ -404,9 +414,17 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
                 const double l1 = fma(m.b0[k], f01, fma(m.b1[k], f11, f21));
                 const double l2 = fma(m.b0[k], f02, fma(m.b1[k], f12, f22));
                 r[k] = fma(l0, m.a0[k], fma(l1, m.a1[k], l2));
+                if (SAMPSON) r[k] = sampson_error(r[k], l0, l1, m.a0[k], m.a1[k], f00, f01, f02, f10, f11, f12);
             }
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
+                if (SAMPSON) {
+                    // r[k] is the Sampson distance and rcut the threshold on it
+                    const bool in = m.live[k] && r[k] < rcut;
+                    cnt[j] += __popcll(__ballot(in));
+                    es[j] += in ? r[k] : 0.0;
+                    continue;
+                }
                 // fl(r*r) < thr  <=>  |r| < rcut (rcut: the smallest double whose rounded square reaches thr).
                 // The compare writes the execution mask itself, so the inlier lanes alone accumulate r*r and the
                 // mask's population count is the inlier count: no select instructions.
@@ -449,7 +467,7 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
 }
 
 // K2 standalone: F read from memory (large H, after k_solve)
-template <int HB, int PPL, int WAVES>
+template <int HB, int PPL, int WAVES, bool SAMPSON>
 __global__ __launch_bounds__(64 * WAVES, 32 / WAVES) void k_score(const double2* __restrict__ p0, const double2* __restrict__ p1,
                                                       int N, const double* __restrict__ Fall, int H, double rcut,
                                                       int32_t* __restrict__ counts, double* __restrict__ errsums) {
@@ -464,7 +482,7 @@ __global__ __launch_bounds__(64 * WAVES, 32 / WAVES) void k_score(const double2*
         s_F[threadIdx.x / 9][threadIdx.x % 9] = Fall[(size_t)h * 9 + threadIdx.x % 9];
     }
     __syncthreads();
-    score_hypotheses<HB, PPL, WAVES>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
+    score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
 }
 
 // K1+K2 fused for small H.  A workgroup owns WAVES hypotheses:
@@ -479,7 +497,7 @@ __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int HB, int PPL, int WAVES, int SAMPLER>
+template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
 __global__ __launch_bounds__(64 * WAVES) void k_ransac(
     const double2* __restrict__ p0, const double2* __restrict__ p1, int N, const int32_t* __restrict__ idx_in,
     uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw, int64_t raw_it0, double rcut,
@@ -526,7 +544,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ransac(
     SLAM_STAMP(2);
     barrier_lds_only();
     SLAM_STAMP(3);
-    score_hypotheses<HB, PPL, WAVES>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
+    score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,6 +577,7 @@ __device__ __forceinline__ Best wave_best(Best b) {
     return b;
 }
 
+template <bool SAMPSON>
 __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
                                                  const double* __restrict__ Fall, int H, int64_t it0,
                                                  const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
@@ -600,7 +619,10 @@ __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ cou
             const double l1 = fma(bb.x, f01, fma(bb.y, f11, f21));
             const double l2 = fma(bb.x, f02, fma(bb.y, f12, f22));
             const double r = fma(l0, a.x, fma(l1, a.y, l2));
-            mask[i] = (fabs(r) < rcut) ? 1 : 0;  // same predicate as the scoring kernels
+            if (SAMPSON)
+                mask[i] = (sampson_error(r, l0, l1, a.x, a.y, f00, f01, f02, f10, f11, f12) < rcut) ? 1 : 0;
+            else
+                mask[i] = (fabs(r) < rcut) ? 1 : 0;  // same predicate as the scoring kernels
         }
     }
 }

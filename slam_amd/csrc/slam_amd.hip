@@ -123,6 +123,13 @@ extern "C" int slam_set_concurrency(slam_ctx* ctx, int lanes) {
     return SLAM_OK;
 }
 
+extern "C" int slam_set_scoring(slam_ctx* ctx, int mode) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, mode == SLAM_SCORE_ALGEBRAIC || mode == SLAM_SCORE_SAMPSON, "unknown scoring mode");
+    ctx->sampson = mode == SLAM_SCORE_SAMPSON;
+    return SLAM_OK;
+}
+
 extern "C" int slam_synchronize(slam_ctx* ctx) {
     if (!ctx) return SLAM_EINVAL;
     return slam_sync_all(ctx);
@@ -335,28 +342,28 @@ static double square_cutoff(double thr) {
     } while (0)
 
 // small H: one fused launch
-template <int SAMPLER>
+template <int SAMPLER, bool SAMPSON>
 static int launch_fused(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
                         int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
     const dim3 grid((H + SLAM_HB - 1) / SLAM_HB);
     const uint32_t* raw = (const uint32_t*)ctx->raw.p;
     int32_t* flags = (int32_t*)ctx->flags.p;
 #define SLAM_CALL(PPL, WAVES)                                                                                         \
-    return slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, WAVES, SAMPLER>, grid, dim3(64 * WAVES), 0, p0, p1, N, \
+    return slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, p0, p1, N, \
                        d_idx, seed, it0, H, raw, ctx->raw_it0, thr, F, counts, errsums, flags)
     SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
 }
 
 // large H: a lane per hypothesis for the solve, then the scoring kernel
-template <int SAMPLER>
+template <int SAMPLER, bool SAMPSON>
 static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
                         int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
     SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SAMPLER>, dim3((H + 63) / 64), dim3(64), 0, p0, p1, N, d_idx, seed, it0,
                          H, (const uint32_t*)ctx->raw.p, ctx->raw_it0, F, (int32_t*)ctx->flags.p));
     const dim3 grid((H + SLAM_HB - 1) / SLAM_HB);
 #define SLAM_CALL(PPL, WAVES)                                                                                        \
-    return slam_launch(ctx, SLAM_K_SCORE, k_score<SLAM_HB, PPL, WAVES>, grid, dim3(64 * WAVES), 0, p0, p1, N,         \
+    return slam_launch(ctx, SLAM_K_SCORE, k_score<SLAM_HB, PPL, WAVES, SAMPSON>, grid, dim3(64 * WAVES), 0, p0, p1, N,         \
                        (const double*)F, H, thr, counts, errsums)
     SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
@@ -367,8 +374,12 @@ static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int
 template <int SAMPLER>
 static int launch_ransac(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
                          int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
-    if (H <= SLAM_FUSED_MAX_H) return launch_fused<SAMPLER>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
-    return launch_split<SAMPLER>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
+    const bool fused = H <= SLAM_FUSED_MAX_H;
+    if (ctx->sampson)
+        return fused ? launch_fused<SAMPLER, true>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums)
+                     : launch_split<SAMPLER, true>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
+    return fused ? launch_fused<SAMPLER, false>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums)
+                 : launch_split<SAMPLER, false>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
 }
 
 static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
@@ -385,7 +396,7 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     if (!d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double))); d_errsums = (double*)ctx->errsums.p; }
     const double2* p0 = (const double2*)d_p0;
     const double2* p1 = (const double2*)d_p1;
-    thr = square_cutoff(thr);  // from here on the threshold is the cutoff on |r|
+    if (!ctx->sampson) thr = square_cutoff(thr);  // algebraic mode: from here on the threshold is the cutoff on |r|
     if (d_idx) {
         SLAM_TRY(launch_ransac<-1>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
     } else if (sampler == SLAM_SAMPLER_CPYTHON) {
@@ -394,8 +405,12 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     } else {
         SLAM_TRY(launch_ransac<SLAM_SAMPLER_COUNTER>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
     }
-    SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select, dim3(1), dim3(1024), 0, (const int32_t*)d_counts,
-                         (const double*)d_errsums, (const double*)d_F_all, H, it0, p0, p1, N, thr, d_record, d_mask));
+    if (ctx->sampson)
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<true>, dim3(1), dim3(1024), 0, (const int32_t*)d_counts,
+                             (const double*)d_errsums, (const double*)d_F_all, H, it0, p0, p1, N, thr, d_record, d_mask));
+    else
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1), dim3(1024), 0, (const int32_t*)d_counts,
+                             (const double*)d_errsums, (const double*)d_F_all, H, it0, p0, p1, N, thr, d_record, d_mask));
     return SLAM_OK;
 }
 
@@ -462,6 +477,81 @@ extern "C" int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, 
     if (errsums) SLAM_HIP(ctx, hipMemcpyAsync(errsums, ctx->errsums.p, (size_t)H * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (F_all) SLAM_HIP(ctx, hipMemcpyAsync(F_all, ctx->F.p, (size_t)H * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return check_flags(ctx);
+}
+
+extern "C" int slam_ransac_f_adaptive(slam_ctx* ctx, const double* p0, const double* p1, int N, int sampler,
+                                      uint64_t seed, int64_t max_iterations, int chunk, double confidence,
+                                      double threshold, double* record, uint8_t* mask, int64_t* iterations_run) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, p0 && p1 && record, "points or record pointer is NULL");
+    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
+    SLAM_REQUIRE(ctx, max_iterations >= 1 && chunk >= 1, "max_iterations < 1 or chunk < 1");
+    SLAM_REQUIRE(ctx, confidence > 0.0 && confidence < 1.0, "confidence must be inside (0, 1)");
+    SLAM_REQUIRE(ctx, sampler == SLAM_SAMPLER_CPYTHON || sampler == SLAM_SAMPLER_COUNTER, "unknown sampler");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t limit = slam_num_hypotheses(N, max_iterations);
+    double *d0, *d1;
+    SLAM_TRY(stage_points(ctx, p0, p1, N, &d0, &d1));
+    SLAM_TRY(slam_reserve(ctx, ctx->mask, (size_t)N));
+    const int hmax = (int)std::min<int64_t>(chunk, limit);
+    SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)hmax * 9 * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)hmax * sizeof(int32_t)));
+    SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)hmax * sizeof(double)));
+    double best[SLAM_REC_LEN];
+    bool have = false;
+    int64_t done = 0, need = limit;
+    double* hrec = ctx->h_small + 160;
+    while (done < need) {
+        const int H = (int)std::min<int64_t>(chunk, limit - done);
+        SLAM_TRY(ransac_enqueue(ctx, d0, d1, N, nullptr, sampler, seed, done, H, threshold, (double*)ctx->record.p, nullptr,
+                                (int32_t*)ctx->counts.p, (double*)ctx->errsums.p, (double*)ctx->F.p));
+        SLAM_HIP(ctx, hipMemcpyAsync(hrec, ctx->record.p, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_TRY(check_flags(ctx));
+        if (have) {
+            double two[2 * SLAM_REC_LEN];
+            memcpy(two, best, sizeof best);
+            memcpy(two + SLAM_REC_LEN, hrec, sizeof best);
+            slam_merge_records(two, 2, best);
+        } else {
+            memcpy(best, hrec, sizeof best);
+            have = true;
+        }
+        done += H;
+        const double w = best[SLAM_REC_COUNT] / (double)N;
+        const double w8 = std::pow(w, 8.0);
+        int64_t est;
+        if (w8 >= 1.0) est = 1;
+        else if (w8 <= 0.0) est = limit;
+        else {
+            const double k = std::ceil(std::log(1.0 - confidence) / std::log1p(-w8));
+            est = k >= (double)limit ? limit : std::max<int64_t>(1, (int64_t)k);
+        }
+        need = std::min(need, std::max(est, (int64_t)1));  // the estimate only ever shortens the run
+        if (done >= limit) break;
+    }
+    memcpy(record, best, sizeof best);
+    if (iterations_run) *iterations_run = done;
+    if (mask) {
+        // the winner's mask: the selection kernel on a one-entry table holding the winner
+        double* dF = (double*)ctx->F.p;
+        int32_t one_count = (int32_t)best[SLAM_REC_COUNT];
+        SLAM_HIP(ctx, hipMemcpyAsync(dF, best + SLAM_REC_F, 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(ctx->counts.p, &one_count, sizeof one_count, hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(ctx->errsums.p, best + SLAM_REC_ERRSUM, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        const double cut = ctx->sampson ? threshold : square_cutoff(threshold);
+        const double2 *q0 = (const double2*)d0, *q1 = (const double2*)d1;
+        if (ctx->sampson)
+            SLAM_TRY(slam_launch(ctx, -1, k_select<true>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
+                                 (const double*)ctx->errsums.p, (const double*)dF, 1, (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
+                                 cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p));
+        else
+            SLAM_TRY(slam_launch(ctx, -1, k_select<false>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
+                                 (const double*)ctx->errsums.p, (const double*)dF, 1, (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
+                                 cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p));
+        SLAM_HIP(ctx, hipMemcpyAsync(mask, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SLAM_OK;
 }
 
 extern "C" int slam_merge_records(const double* records, int n_records, double* out) {
@@ -658,6 +748,11 @@ extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* p
     SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
     SLAM_REQUIRE(ctx, iterations >= 1, "iterations < 1");
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    struct KeepScoring {  // the pair pipeline always scores with the reference's residual
+        slam_ctx* c; bool was;
+        explicit KeepScoring(slam_ctx* c_) : c(c_), was(c_->sampson) { c->sampson = false; }
+        ~KeepScoring() { c->sampson = was; }
+    } keep_scoring(ctx);
     const int H = (int)slam_num_hypotheses(N, iterations);
     const size_t bytes = (size_t)N * 2 * sizeof(double), stride = (bytes + 63) & ~(size_t)63;
     // pts: raw0 | raw1 | norm0 | norm1
@@ -736,6 +831,9 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
         maxH = std::max(maxH, (int)slam_num_hypotheses(n, iterations));
     }
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const bool scoring_was = ctx->sampson;  // the pair pipeline always scores with the reference's residual
+    ctx->sampson = false;
+    struct Restore { slam_ctx* c; bool v; ~Restore() { c->sampson = v; } } restore_scoring{ctx, scoring_was};
     const int64_t total = offsets[P];
     const bool lanes = ctx->stream == ctx->own_stream;  // a caller-supplied stream keeps everything in order on it
     const int L = lanes ? SLAM_LANES : 1;

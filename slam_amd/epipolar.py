@@ -38,11 +38,14 @@ def calculate_fundamental_matrix(img0_points, img1_points):
 
 
 def ransac_detailed(img0_points, img1_points, iterations=1000, idx=None, sampler=_lib.SAMPLER_CPYTHON,
-                    seed=_lib.SEED_BASE, it0=0, threshold=_lib.DEFAULT_THRESHOLD, per_hypothesis=False, ctx=None):
+                    seed=_lib.SEED_BASE, it0=0, threshold=_lib.DEFAULT_THRESHOLD, per_hypothesis=False, ctx=None,
+                    scoring=_lib.SCORE_ALGEBRAIC):
     """Run the RANSAC loop of src/epipolar.py:54-84 and return everything it computes.
 
     idx: optional (H,8) pre-drawn index sets (then ``iterations`` is ignored); otherwise H =
     min(iterations, C(N,8)) samples are drawn on the GPU with ``sampler``.
+    scoring: _lib.SCORE_ALGEBRAIC is the reference's residual; _lib.SCORE_SAMPSON (an extension) scores with the
+    Sampson distance, to which ``threshold`` then applies.
     """
     p0, p1 = _pair(img0_points, img1_points)
     ctx = ctx or _lib.default_context()
@@ -59,11 +62,39 @@ def ransac_detailed(img0_points, img1_points, iterations=1000, idx=None, sampler
     counts = np.empty(H, dtype=np.int32) if per_hypothesis else None
     errsums = np.empty(H) if per_hypothesis else None
     Fs = np.empty((H, 3, 3)) if per_hypothesis else None
-    ctx.check(ctx.lib.slam_ransac_f(ctx.handle, ptr(p0), ptr(p1), N, ptr(idx), int(sampler), int(seed), int(it0), H,
-                                    float(threshold), ptr(record), ptr(mask), ptr(counts), ptr(errsums), ptr(Fs)))
+    ctx.check(ctx.lib.slam_set_scoring(ctx.handle, int(scoring)))
+    try:
+        ctx.check(ctx.lib.slam_ransac_f(ctx.handle, ptr(p0), ptr(p1), N, ptr(idx), int(sampler), int(seed), int(it0), H,
+                                        float(threshold), ptr(record), ptr(mask), ptr(counts), ptr(errsums), ptr(Fs)))
+    finally:
+        ctx.lib.slam_set_scoring(ctx.handle, _lib.SCORE_ALGEBRAIC)
     return dict(F=record[REC_F:REC_F + 9].reshape(3, 3).copy(), best_index=int(record[REC_INDEX]),
                 best_count=int(record[REC_COUNT]), best_errsum=float(record[REC_ERRSUM]), best_mask=mask.astype(bool),
                 counts=counts, errsums=errsums, F_all=Fs, H=H, record=record)
+
+
+def ransac_adaptive(img0_points, img1_points, max_iterations=1000, confidence=0.99, chunk=2048,
+                    sampler=_lib.SAMPLER_CPYTHON, seed=_lib.SEED_BASE, threshold=_lib.DEFAULT_THRESHOLD, ctx=None,
+                    scoring=_lib.SCORE_ALGEBRAIC):
+    """RANSAC with the standard stopping rule (an extension: the reference always runs every iteration).  Scores
+    iterations 0, 1, ... in chunks and stops once ceil(log(1-confidence)/log(1-w^8)) iterations have been scored, w
+    being the best inlier ratio so far.  The result equals ransac_detailed(iterations=r["iterations_run"])."""
+    p0, p1 = _pair(img0_points, img1_points)
+    ctx = ctx or _lib.default_context()
+    N = len(p0)
+    record = np.empty(REC_LEN)
+    mask = np.empty(N, dtype=np.uint8)
+    ran = np.zeros(1, dtype=np.int64)
+    ctx.check(ctx.lib.slam_set_scoring(ctx.handle, int(scoring)))
+    try:
+        ctx.check(ctx.lib.slam_ransac_f_adaptive(ctx.handle, ptr(p0), ptr(p1), N, int(sampler), int(seed), int(max_iterations),
+                                                 int(chunk), float(confidence), float(threshold), ptr(record), ptr(mask),
+                                                 ptr(ran)))
+    finally:
+        ctx.lib.slam_set_scoring(ctx.handle, _lib.SCORE_ALGEBRAIC)
+    return dict(F=record[REC_F:REC_F + 9].reshape(3, 3).copy(), best_index=int(record[REC_INDEX]),
+                best_count=int(record[REC_COUNT]), best_errsum=float(record[REC_ERRSUM]), best_mask=mask.astype(bool),
+                iterations_run=int(ran[0]), record=record)
 
 
 def calculate_fundamental_matrix_with_ransac(img0_points, img1_points, iterations=1000):

@@ -31,6 +31,12 @@ enum {
 //   singular value of D' ; Y = diag(m) y ; X = Y[0..2] / Y[3]
 // P0, P1 are wave-uniform pointers (scalar loads).
 // ------------------------------------------------------------------------------------------------
+// 1/x to within an ulp, with 1/(+-0) = +-inf like the division it stands for
+__device__ __forceinline__ double rcp_like_division(double x) {
+    const double r = fast_rcp(x);
+    return x == 0.0 ? __builtin_amdgcn_rcp(x) : r;
+}
+
 __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, const double* __restrict__ P1, double u0,
                                                 double v0, double u1, double v1, double (&X)[3]) {
     double D[4][4], m[4];
@@ -43,9 +49,9 @@ __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, c
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = fmax(fmax(fabs(D[i][0]), fabs(D[i][1])), fmax(fabs(D[i][2]), fabs(D[i][3])));
-    double im[4];
+    double im[4];  // reciprocals to within an ulp (the points are compared to 1e-5)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) im[j] = 1.0 / m[j];
+    for (int j = 0; j < 4; ++j) im[j] = rcp_like_division(m[j]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -56,9 +62,10 @@ __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, c
     double Y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Y[i] = m[i] * yv[i];
-    X[0] = Y[0] / Y[3];
-    X[1] = Y[1] / Y[3];
-    X[2] = Y[2] / Y[3];
+    const double iy = rcp_like_division(Y[3]);
+    X[0] = Y[0] * iy;
+    X[1] = Y[1] * iy;
+    X[2] = Y[2] * iy;
 }
 
 struct Cams {  // kernel argument: the first three rows of both camera matrices

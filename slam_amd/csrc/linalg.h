@@ -286,37 +286,38 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
 // sweeps on A itself then polish the last column (they do not see G's squared condition number).
 // angle_tol: rotation angle below which a pair counts as converged.
 __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double angle_tol, double (&y)[4]) {
+    // (the warm start is written with explicit fma: it only has to be good to a few digits)
     double g[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = i; j < 4; ++j) {
-            g[i][j] = A[0][i] * A[0][j] + A[1][i] * A[1][j] + A[2][i] * A[2][j] + A[3][i] * A[3][j];
+            g[i][j] = fma(A[0][i], A[0][j], fma(A[1][i], A[1][j], fma(A[2][i], A[2][j], A[3][i] * A[3][j])));
             g[j][i] = g[i][j];
         }
     // 2 x 2 minors of rows (0,1) and rows (2,3) of a symmetric matrix with diagonal d0..d3
     double s0, s1, s2, s3, s4, s5, c0, c1, c2, c3, c4, c5;
     auto minors = [&](double d0, double d1, double d2, double d3) {
-        s0 = d0 * d1 - g[0][1] * g[0][1];
-        s1 = d0 * g[1][2] - g[0][1] * g[0][2];
-        s2 = d0 * g[1][3] - g[0][1] * g[0][3];
-        s3 = g[0][1] * g[1][2] - d1 * g[0][2];
-        s4 = g[0][1] * g[1][3] - d1 * g[0][3];
-        s5 = g[0][2] * g[1][3] - g[1][2] * g[0][3];
+        s0 = fma(d0, d1, -g[0][1] * g[0][1]);
+        s1 = fma(d0, g[1][2], -g[0][1] * g[0][2]);
+        s2 = fma(d0, g[1][3], -g[0][1] * g[0][3]);
+        s3 = fma(g[0][1], g[1][2], -d1 * g[0][2]);
+        s4 = fma(g[0][1], g[1][3], -d1 * g[0][3]);
+        s5 = fma(g[0][2], g[1][3], -g[1][2] * g[0][3]);
         c0 = s5;
-        c1 = g[0][2] * g[2][3] - d2 * g[0][3];
-        c2 = g[0][2] * d3 - g[2][3] * g[0][3];
-        c3 = g[1][2] * g[2][3] - d2 * g[1][3];
-        c4 = g[1][2] * d3 - g[2][3] * g[1][3];
-        c5 = d2 * d3 - g[2][3] * g[2][3];
+        c1 = fma(g[0][2], g[2][3], -d2 * g[0][3]);
+        c2 = fma(g[0][2], d3, -g[2][3] * g[0][3]);
+        c3 = fma(g[1][2], g[2][3], -d2 * g[1][3]);
+        c4 = fma(g[1][2], d3, -g[2][3] * g[1][3]);
+        c5 = fma(d2, d3, -g[2][3] * g[2][3]);
     };
     minors(g[0][0], g[1][1], g[2][2], g[3][3]);
     // characteristic polynomial x^4 - k3 x^3 + k2 x^2 - k1 x + k0
-    const double k0 = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-    const double k1 = (g[1][1] * c5 - g[1][2] * c4 + g[1][3] * c3) + (g[0][0] * c5 - g[0][2] * c2 + g[0][3] * c1) +
-                      (g[3][3] * s0 - g[1][3] * s2 + g[0][3] * s4) + (g[2][2] * s0 - g[1][2] * s1 + g[0][2] * s3);
-    const double k2 = s0 + c5 + (g[0][0] * g[2][2] - g[0][2] * g[0][2]) + (g[0][0] * g[3][3] - g[0][3] * g[0][3]) +
-                      (g[1][1] * g[2][2] - g[1][2] * g[1][2]) + (g[1][1] * g[3][3] - g[1][3] * g[1][3]);
+    const double k0 = fma(s0, c5, fma(-s1, c4, fma(s2, c3, fma(s3, c2, fma(-s4, c1, s5 * c0)))));
+    const double k1 = fma(g[1][1], c5, fma(-g[1][2], c4, g[1][3] * c3)) + fma(g[0][0], c5, fma(-g[0][2], c2, g[0][3] * c1)) +
+                      fma(g[3][3], s0, fma(-g[1][3], s2, g[0][3] * s4)) + fma(g[2][2], s0, fma(-g[1][2], s1, g[0][2] * s3));
+    const double k2 = s0 + c5 + fma(g[0][0], g[2][2], -g[0][2] * g[0][2]) + fma(g[0][0], g[3][3], -g[0][3] * g[0][3]) +
+                      fma(g[1][1], g[2][2], -g[1][2] * g[1][2]) + fma(g[1][1], g[3][3], -g[1][3] * g[1][3]);
     const double k3 = g[0][0] + g[1][1] + g[2][2] + g[3][3];
     double lam = 0.0;
 #pragma unroll
@@ -328,16 +329,16 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
     const double d0 = g[0][0] - lam, d1 = g[1][1] - lam, d2 = g[2][2] - lam, d3 = g[3][3] - lam;
     minors(d0, d1, d2, d3);
     // adjugate of the shifted matrix (symmetric): a multiple of v v^T
-    const double j00 = d1 * c5 - g[1][2] * c4 + g[1][3] * c3;
-    const double j01 = -g[0][1] * c5 + g[0][2] * c4 - g[0][3] * c3;
-    const double j02 = g[1][3] * s5 - g[2][3] * s4 + d3 * s3;
-    const double j03 = -g[1][2] * s5 + d2 * s4 - g[2][3] * s3;
-    const double j11 = d0 * c5 - g[0][2] * c2 + g[0][3] * c1;
-    const double j12 = -g[0][3] * s5 + g[2][3] * s2 - d3 * s1;
-    const double j13 = g[0][2] * s5 - d2 * s2 + g[2][3] * s1;
-    const double j22 = g[0][3] * s4 - g[1][3] * s2 + d3 * s0;
-    const double j23 = -g[0][2] * s4 + g[1][2] * s2 - g[2][3] * s0;
-    const double j33 = g[0][2] * s3 - g[1][2] * s1 + d2 * s0;
+    const double j00 = fma(d1, c5, fma(-g[1][2], c4, g[1][3] * c3));
+    const double j01 = fma(-g[0][1], c5, fma(g[0][2], c4, -g[0][3] * c3));
+    const double j02 = fma(g[1][3], s5, fma(-g[2][3], s4, d3 * s3));
+    const double j03 = fma(-g[1][2], s5, fma(d2, s4, -g[2][3] * s3));
+    const double j11 = fma(d0, c5, fma(-g[0][2], c2, g[0][3] * c1));
+    const double j12 = fma(-g[0][3], s5, fma(g[2][3], s2, -d3 * s1));
+    const double j13 = fma(g[0][2], s5, fma(-d2, s2, g[2][3] * s1));
+    const double j22 = fma(g[0][3], s4, fma(-g[1][3], s2, d3 * s0));
+    const double j23 = fma(-g[0][2], s4, fma(g[1][2], s2, -g[2][3] * s0));
+    const double j33 = fma(g[0][2], s3, fma(-g[1][2], s1, d2 * s0));
     const double a0 = fabs(j00), a1 = fabs(j11), a2 = fabs(j22), a3 = fabs(j33);
     const bool p0 = (a0 >= a1) && (a0 >= a2) && (a0 >= a3);
     const bool p1 = !p0 && (a1 >= a2) && (a1 >= a3);
@@ -347,7 +348,7 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
     v[1] = p0 ? j01 : p1 ? j11 : p2 ? j12 : j13;
     v[2] = p0 ? j02 : p1 ? j12 : p2 ? j22 : j23;
     v[3] = p0 ? j03 : p1 ? j13 : p2 ? j23 : j33;
-    const double vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    const double vn2 = fma(v[0], v[0], fma(v[1], v[1], fma(v[2], v[2], v[3] * v[3])));
     const bool usable = (vn2 > 0.0) && (vn2 < 1e300);  // false for NaN, zero or overflow: start from the identity
     const double vi = rsqrt(vn2);
 #pragma unroll
@@ -371,7 +372,7 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
     // B = A H = A - beta (A w) w^T
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double aw = beta * (A[r][0] * w[0] + A[r][1] * w[1] + A[r][2] * w[2] + A[r][3] * w[3]);
+        const double aw = beta * fma(A[r][0], w[0], fma(A[r][1], w[1], fma(A[r][2], w[2], A[r][3] * w[3])));
 #pragma unroll
         for (int j = 0; j < 4; ++j) A[r][j] = fma(-aw, w[j], A[r][j]);
     }
@@ -387,7 +388,7 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
     jacobi_sweeps<4, 4, true>(A, V, 30, angle_tol, !usable);
     double n2[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) n2[j] = A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j] + A[3][j] * A[3][j];
+    for (int j = 0; j < 4; ++j) n2[j] = fma(A[0][j], A[0][j], fma(A[1][j], A[1][j], fma(A[2][j], A[2][j], A[3][j] * A[3][j])));
     // a converged least column cannot be longer than any other column (||A v|| >= sigma_min for unit v); if it is,
     // the start was poor: converge every pair and take the shortest column
     if (__any(n2[3] > n2[0] || n2[3] > n2[1] || n2[3] > n2[2] || !usable)) {

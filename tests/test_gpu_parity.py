@@ -280,7 +280,8 @@ def test_triangulate_large_against_c_restatement_and_chunking(ctx):
     X = triangulation.triangulate_points_from_pose(P0, P1, d["pts0"], d["pts1"])
     ref = co.triangulate(P0, P1, d["pts0"], d["pts1"], threads=8)
     rel = np.abs(X - ref) / np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max(axis=1, keepdims=True))
-    assert np.quantile(rel, 0.999) < 1e-9 and rel.max() < X_TOL
+    assert rel.max() < 1e-7              # the bar is X_TOL = 1e-5; the kernel is expected to stay far inside it
+    assert np.quantile(rel, 0.999) < 1e-9
     # size-independent property: a call on a slice equals the slice of the call, bit for bit
     a = triangulation.triangulate_points_from_pose(P0, P1, d["pts0"][:70001], d["pts1"][:70001])
     b = triangulation.triangulate_points_from_pose(P0, P1, d["pts0"][70001:], d["pts1"][70001:])

@@ -1,0 +1,37 @@
+"""Bulk triangulation (four candidates per point) on device-resident points: kernel time per launch."""
+import argparse
+import ctypes as C
+import sys
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+from slam_amd import _lib, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("-n", type=int, default=1 << 22)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+ctx = _lib.default_context()
+lib = ctx.lib
+dev = torch.device("cuda", ctx.device)
+big = synth.make_pair(1 << 16, 0.0, seed=5)
+reps = a.n // (1 << 16)
+p0 = torch.from_numpy(big["pts0"]).to(dev).repeat(reps, 1).contiguous()
+p1 = torch.from_numpy(big["pts1"]).to(dev).repeat(reps, 1).contiguous()
+torch.manual_seed(5)
+p1 += torch.rand_like(p1) * 0.25
+E = np.ascontiguousarray(synth.essential_from_motion(big["R"], big["t"]))
+K = np.ascontiguousarray(big["K"])
+cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
+lib.slam_profile_enable(ctx.handle, 1)
+for i in range(a.steps + 1):
+    if i == 1:
+        lib.slam_profile_reset(ctx.handle)
+    ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0.data_ptr(), p1.data_ptr(), a.n, cnt.data_ptr()))
+ms, n = C.c_double(), C.c_int64()
+lib.slam_profile_read(ctx.handle, _lib.K_TRIANGULATE, C.byref(ms), C.byref(n))
+t = ms.value / n.value
+print(f"n={a.n}: k_triangulate4 {t:.3f} ms, {a.n/t/1e6:.2f} G points/s, {4*a.n/t/1e6:.2f} G candidate triangulations/s, counts {cnt.cpu().tolist()}")

@@ -282,7 +282,7 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
 //
 // Warm start as in rank2_project: G = A^T A; lambda = smallest root of its characteristic quartic by Newton from 0
 // (monotone from below); the largest column of adj(G - lambda I) is parallel to the wanted vector v; a Householder
-// reflector that maps a unit axis onto v supplies an orthonormal basis with v as its last column.  One-sided Jacobi
+// reflector that maps the last unit axis onto v supplies an orthonormal basis with v as its last column.  One-sided Jacobi
 // sweeps on A itself then polish the last column (they do not see G's squared condition number).
 // angle_tol: rotation angle below which a pair counts as converged.
 __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double angle_tol, double (&y)[4]) {
@@ -353,17 +353,11 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
     const double vi = rsqrt(vn2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = usable ? v[i] * vi : (i == 3 ? 1.0 : 0.0);
-    // Householder reflector H = I - w w^T / (1 + |v_k|), w = v + sign(v_k) e_k, k = largest |v_k|: column k of H is
-    // -sign(v_k) v and the other columns complete an orthonormal basis.  V = H with columns k and 3 exchanged.
-    const double q0 = fabs(v[0]), q1 = fabs(v[1]), q2 = fabs(v[2]), q3 = fabs(v[3]);
-    const bool m0 = (q0 >= q1) && (q0 >= q2) && (q0 >= q3);
-    const bool m1 = !m0 && (q1 >= q2) && (q1 >= q3);
-    const bool m2 = !m0 && !m1 && (q2 >= q3);
-    const bool m3 = !m0 && !m1 && !m2;
-    const double vk = m0 ? v[0] : m1 ? v[1] : m2 ? v[2] : v[3];
-    const double sg = vk >= 0.0 ? 1.0 : -1.0;
-    double w[4] = {v[0] + (m0 ? sg : 0.0), v[1] + (m1 ? sg : 0.0), v[2] + (m2 ? sg : 0.0), v[3] + (m3 ? sg : 0.0)};
-    const double beta = fast_rcp(1.0 + fabs(vk));
+    // Householder reflector H = I - w w^T / (1 + |v_3|) with w = v + sign(v_3) e_3: its last column is -sign(v_3) v and
+    // the other columns complete an orthonormal basis.  w^T w = 2 (1 + |v_3|) >= 2 whatever v_3 is: no cancellation.
+    const double sg = v[3] >= 0.0 ? 1.0 : -1.0;
+    const double w[4] = {v[0], v[1], v[2], v[3] + sg};
+    const double beta = fast_rcp(1.0 + fabs(v[3]));
     double V[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -375,15 +369,6 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
         const double aw = beta * fma(A[r][0], w[0], fma(A[r][1], w[1], fma(A[r][2], w[2], A[r][3] * w[3])));
 #pragma unroll
         for (int j = 0; j < 4; ++j) A[r][j] = fma(-aw, w[j], A[r][j]);
-    }
-    // bring the v column (k) to position 3
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double ak = m0 ? A[r][0] : m1 ? A[r][1] : m2 ? A[r][2] : A[r][3];
-        const double vk_ = m0 ? V[r][0] : m1 ? V[r][1] : m2 ? V[r][2] : V[r][3];
-        const double a3_ = A[r][3], v3_ = V[r][3];
-        A[r][0] = m0 ? a3_ : A[r][0]; A[r][1] = m1 ? a3_ : A[r][1]; A[r][2] = m2 ? a3_ : A[r][2]; A[r][3] = ak;
-        V[r][0] = m0 ? v3_ : V[r][0]; V[r][1] = m1 ? v3_ : V[r][1]; V[r][2] = m2 ? v3_ : V[r][2]; V[r][3] = vk_;
     }
     jacobi_sweeps<4, 4, true>(A, V, 30, angle_tol, !usable);
     double n2[4];

@@ -69,6 +69,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # RCCL sets its communicator up at the first collective.  That has to happen BEFORE the library creates its
+        # streams: created in between, the library's three internal streams end up sharing hardware queues and a step
+        # costs 12.5 us instead of 9.4 us (measured with tools/distprobe2.py).
+        torch.cuda.set_device(local)
+        dist.barrier()
+        torch.cuda.synchronize()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -77,11 +83,21 @@ def main():
     ctx = _lib.Context(local)
     lib = ctx.lib
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
+    def sync_local():
         ctx.check(lib.slam_synchronize(ctx.handle))
         torch.cuda.synchronize()
+
+    def barrier():
+        """Opening bracket of a timed region: this rank's queued work has finished and every rank is here."""
+        sync_local()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def stop_clock():
+        """Closing bracket: barrier + synchronise, then read the clock."""
+        barrier()
+        return time.perf_counter()
 
     # ---- inputs: one frame pair per rank, normalised as the reference's caller does, resident in HBM
     pair = synth.make_pair(N_MATCHES, OUTLIERS, seed=2 + rank)
@@ -108,14 +124,20 @@ def main():
         if rc:
             ctx.check(rc)
 
+    # A step lasts about 10 us, so a short run would be timed while the GPU's clocks still ramp up (the first tens of
+    # milliseconds of work run ~35 % slower): bring the device to its steady state first, whatever W is.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.25:
+        for _ in range(200):
+            step()
+        ctx.check(lib.slam_synchronize(ctx.handle))
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = stop_clock() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -129,8 +151,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
-    dt_serial = time.perf_counter() - t0
+    dt_serial = stop_clock() - t0
 
     # ---- roofline of the scoring kernel: per-launch durations from HIP events on the library's stream
     ctx.check(lib.slam_profile_enable(ctx.handle, 1))
@@ -186,8 +207,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(20):
             big_step()
-        barrier()
-        bdt = (time.perf_counter() - t0) / 20
+        bdt = (stop_clock() - t0) / 20
         ms, n = C.c_double(0), C.c_int64(0)
         ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms), C.byref(n)))
         ctx.check(lib.slam_profile_enable(ctx.handle, 0))
@@ -206,8 +226,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(10):
             big_step()
-        barrier()
-        sdt_ = (time.perf_counter() - t0) / 10
+        sdt_ = (stop_clock() - t0) / 10
         ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms), C.byref(n)))
         ctx.check(lib.slam_profile_enable(ctx.handle, 0))
         ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_ALGEBRAIC))
@@ -248,8 +267,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(3):
             who, win = shard_step()
-        barrier()
-        sdt = (time.perf_counter() - t0) / 3
+        sdt = (stop_clock() - t0) / 3
         if use_dist:
             t = torch.tensor([sdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -306,8 +324,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(tsteps):
             tri_step()
-        barrier()
-        tdt = time.perf_counter() - t0
+        tdt = stop_clock() - t0
         ms, n = C.c_double(0), C.c_int64(0)
         ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_TRIANGULATE, C.byref(ms), C.byref(n)))
         ctx.check(lib.slam_profile_enable(ctx.handle, 0))
@@ -341,8 +358,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         res = pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)
-        barrier()
-        bdt = time.perf_counter() - t0
+        bdt = stop_clock() - t0
         t0 = time.perf_counter()
         one = [pipeline.initialise_pair(a_, b_, Kb, iterations=IB, ctx=ctx) for a_, b_ in plist[:10]]
         sdt = (time.perf_counter() - t0) / 10
@@ -382,8 +398,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(ksteps):
             track_step()
-        barrier()
-        kdt = (time.perf_counter() - t0) / ksteps
+        kdt = (stop_clock() - t0) / ksteps
         ctx.check(lib.slam_profile_enable(ctx.handle, 1))
         ctx.check(lib.slam_profile_reset(ctx.handle))
         for _ in range(ksteps):
@@ -435,8 +450,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(msteps):
             match_step()
-        barrier()
-        mdt_ = (time.perf_counter() - t0) / msteps
+        mdt_ = (stop_clock() - t0) / msteps
         ctx.check(lib.slam_profile_enable(ctx.handle, 1))
         ctx.check(lib.slam_profile_reset(ctx.handle))
         for _ in range(msteps):

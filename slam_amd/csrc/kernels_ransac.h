@@ -498,28 +498,24 @@ __device__ __forceinline__ void barrier_lds_only() {
 }
 
 template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
-__global__ __launch_bounds__(64 * WAVES) void k_ransac(
+__global__ __launch_bounds__(64 * WAVES, 32 / WAVES) void k_ransac(
     const double2* __restrict__ p0, const double2* __restrict__ p1, int N, const int32_t* __restrict__ idx_in,
     uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw, int64_t raw_it0, double rcut,
     double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags) {
-    static_assert(HB <= WAVES && HB <= 64, "one sampling wave and one solving lane per hypothesis");
+    static_assert(HB == 8 && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves eight hypotheses, eight lanes each");
     __shared__ double s_F[HB][9];
     __shared__ double s_err[HB][WAVES];
     __shared__ int s_cnt[HB][WAVES];
     __shared__ int32_t s_sel[HB][8];
     __shared__ int32_t s_scratch[HB][16];
     __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * HB : 1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the branches on it below are scalar branches
     const int h0 = blockIdx.x * HB;
     SLAM_STAMP(0);
-    // the sampler's word is requested first: loads return in order, so it must not queue behind the matches
     const int hs = min(h0 + min(wave, HB - 1), H - 1);  // surplus waves redo a hypothesis; their results are dropped
     uint32_t word = 0;
     if (SAMPLER == SLAM_SAMPLER_CPYTHON) word = raw[(size_t)(it0 + hs - raw_it0) * SLAM_RAW_WORDS + lane];
-    asm volatile("" ::: "memory");  // keep the word's load ahead of the matches' loads
-    MatchChunk<PPL, WAVES> first;
-    first.load(p0, p1, N, 0);  // stays in flight through the sample and solve phases
-    asm volatile("" : "+v"(word));  // the word is consumed here (waits for the oldest load only); nothing sinks past
     if (wave < HB) {
         const bool ok = indices_for_wave<SAMPLER>(hs, N, word, idx_in, seed, it0, raw, raw_it0,
                                                   s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * wave : 0),
@@ -528,20 +524,32 @@ __global__ __launch_bounds__(64 * WAVES) void k_ransac(
     }
     barrier_lds_only();
     SLAM_STAMP(1);
-    if (tid < HB) {
-        int32_t sel[8];
+    // Wave 0 solves the workgroup's eight hypotheses with all of its lanes, eight lanes per hypothesis, one column
+    // of the 9 x 8 system per lane (bit-identical to the one-lane solve of k_solve).  The matches of the first
+    // chunk are requested by the other waves now and by wave 0 after its solve: inside the solve they would only
+    // hold 64 registers, and with at most 128 two workgroups share a CU - one scores while the other one solves.
+    MatchChunk<PPL, WAVES> first;
+    if (wave == 0) {
+        const int g = lane >> 3, c = lane & 7;
+        const int i = min(max(s_sel[g][c], 0), N - 1);  // never read outside the arrays, whatever idx holds
+        const double2 a = p0[i], b = p1[i];
+        double col[9] = {b.x * a.x, b.x * a.y, b.x, b.y * a.x, b.y * a.y, b.y, a.x, a.y, 1.0};
+        double f[9], F[9];
+        null_vector_9x8_by_eight_lanes(col, c, f);
+        rank2_project(f, F);
+        if (c == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sel[q] = s_sel[tid][q];
-        double F[9];
-        solve_from_indices(p0, p1, N, sel, F);
+            for (int q = 0; q < 9; ++q) s_F[g][q] = F[q];
+            if (h0 + g < H) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) s_F[tid][i] = F[i];
-        if (h0 + tid < H) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Fout[(size_t)(h0 + tid) * 9 + i] = F[i];
+                for (int q = 0; q < 9; ++q) Fout[(size_t)(h0 + g) * 9 + q] = F[q];
+            }
         }
+        SLAM_STAMP(2);
+        first.load(p0, p1, N, 0);
+    } else {
+        first.load(p0, p1, N, 0);  // in flight while wave 0 solves
     }
-    SLAM_STAMP(2);
     barrier_lds_only();
     SLAM_STAMP(3);
     score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);

@@ -180,6 +180,86 @@ __device__ __forceinline__ void null_vector_9x8(double (&A)[9][8], double (&n)[9
     }
 }
 
+// The same null vector computed by EIGHT lanes per system (eight systems per wave): lane c of a group of eight
+// consecutive lanes holds column c of the 9 x 8 matrix (a[r] = A[r][c]).  Every scalar operation of
+// null_vector_9x8 happens exactly once per column and in the same order, only on the lane that owns the column
+// (the reflector of step j on lane j, its application to column c on lane c), so the result is bit-identical; the
+// reflector travels to the other lanes of its group through ds_swizzle.  All 64 lanes must be active.
+template <int J>
+__device__ __forceinline__ double bcast8(double x) {  // x of lane J of each group of eight lanes
+    constexpr int pattern = (J << 5) | 0x18;          // bit mode: lane' = (lane & 0b11000) | J
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pattern);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pattern);
+    return __hiloint2double(hi, lo);
+}
+
+template <int J>
+__device__ __forceinline__ void null9x8_forward_step(double (&a)[9], int c, double& beta_own) {
+    // every lane forms the reflector of ITS column at row J; only lane J's is used
+    double sigma = 0.0;
+#pragma unroll
+    for (int r = J + 1; r < 9; ++r) sigma = fma(a[r], a[r], sigma);
+    const double x0 = a[J];
+    const double s2 = fma(x0, x0, sigma);
+    const double normx = (s2 > 0.0) ? s2 * rsqrt(s2) : 0.0;
+    const double alpha = (x0 >= 0.0) ? -normx : normx;
+    const double v0 = x0 - alpha;
+    const double vtv = fma(v0, v0, sigma);
+    const double bj = (vtv > 0.0) ? 2.0 * fast_rcp(vtv) : 0.0;
+    if (c == J) { a[J] = v0; beta_own = bj; }
+    const double rv0 = bcast8<J>(v0), rb = bcast8<J>(bj);
+    double tail[9];
+#pragma unroll
+    for (int r = J + 1; r < 9; ++r) tail[r] = bcast8<J>(a[r]);
+    if (c > J) {
+        double s = rv0 * a[J];
+#pragma unroll
+        for (int r = J + 1; r < 9; ++r) s = fma(tail[r], a[r], s);
+        s *= rb;
+        a[J] = fma(-s, rv0, a[J]);
+#pragma unroll
+        for (int r = J + 1; r < 9; ++r) a[r] = fma(-s, tail[r], a[r]);
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void null9x8_backward_step(const double (&a)[9], double beta_own, double (&n)[9]) {
+    const double rv0 = bcast8<J>(a[J]), rb = bcast8<J>(beta_own);
+    double tail[9];
+#pragma unroll
+    for (int r = J + 1; r < 9; ++r) tail[r] = bcast8<J>(a[r]);
+    double s = rv0 * n[J];
+#pragma unroll
+    for (int r = J + 1; r < 9; ++r) s = fma(tail[r], n[r], s);
+    s *= rb;
+    n[J] = fma(-s, rv0, n[J]);
+#pragma unroll
+    for (int r = J + 1; r < 9; ++r) n[r] = fma(-s, tail[r], n[r]);
+}
+
+// a: this lane's column (destroyed); c = lane & 7; n: the null vector, the same on the eight lanes of a group
+__device__ __forceinline__ void null_vector_9x8_by_eight_lanes(double (&a)[9], int c, double (&n)[9]) {
+    double beta_own = 0.0;
+    null9x8_forward_step<0>(a, c, beta_own);
+    null9x8_forward_step<1>(a, c, beta_own);
+    null9x8_forward_step<2>(a, c, beta_own);
+    null9x8_forward_step<3>(a, c, beta_own);
+    null9x8_forward_step<4>(a, c, beta_own);
+    null9x8_forward_step<5>(a, c, beta_own);
+    null9x8_forward_step<6>(a, c, beta_own);
+    null9x8_forward_step<7>(a, c, beta_own);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) n[r] = (r == 8) ? 1.0 : 0.0;
+    null9x8_backward_step<7>(a, beta_own, n);
+    null9x8_backward_step<6>(a, beta_own, n);
+    null9x8_backward_step<5>(a, beta_own, n);
+    null9x8_backward_step<4>(a, beta_own, n);
+    null9x8_backward_step<3>(a, beta_own, n);
+    null9x8_backward_step<2>(a, beta_own, n);
+    null9x8_backward_step<1>(a, beta_own, n);
+    null9x8_backward_step<0>(a, beta_own, n);
+}
+
 // Closest rank-2 matrix (Frobenius) of f / ||f||_F :  U diag(s0, s1, 0) V^T.
 // With B = f V (columns sigma_i u_i) this is the sum over the two largest columns of B_i v_i^T.
 //

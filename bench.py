@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--tri-points", type=int, default=1 << 24)
-    ap.add_argument("--lanes", type=int, default=3, help="independent steps the library may keep in flight (1..3)")
+    ap.add_argument("--lanes", type=int, default=4, help="independent steps the library may keep in flight (1..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true")
     args = ap.parse_args()
@@ -70,7 +70,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         # RCCL sets its communicator up at the first collective.  That has to happen BEFORE the library creates its
-        # streams: created in between, the library's three internal streams end up sharing hardware queues and a step
+        # streams: created in between, the library's internal streams end up sharing hardware queues and a step
         # costs 12.5 us instead of 9.4 us (measured with tools/distprobe2.py).
         torch.cuda.set_device(local)
         dist.barrier()
@@ -113,14 +113,22 @@ def main():
     masks = [torch.zeros(N_MATCHES, dtype=torch.uint8, device=dev) for _ in range(LANES)]
     d_rec, d_mask = recs[0], masks[0]
     torch.cuda.synchronize()
+    # One prepared call per output buffer: the 15 arguments are marshalled once instead of in every step (ctypes needs
+    # about 2 us for them, as much as the two kernel launches cost).
+    jobs = []
+    for k in range(LANES):
+        j = C.c_void_p()
+        ctx.check(lib.slam_ransac_job_create(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None,
+                                             _lib.SAMPLER_CPYTHON, _lib.SEED_BASE, 0, N_HYP, _lib.DEFAULT_THRESHOLD,
+                                             recs[k].data_ptr(), masks[k].data_ptr(), None, None, None, C.byref(j)))
+        jobs.append(j)
     calls = [0]
+    run = lib.slam_job_run
 
     def step():
-        k = calls[0] % LANES
-        calls[0] += 1
-        rc = lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None, _lib.SAMPLER_CPYTHON,
-                                   _lib.SEED_BASE, 0, N_HYP, _lib.DEFAULT_THRESHOLD, recs[k].data_ptr(), masks[k].data_ptr(),
-                                   None, None, None)
+        k = calls[0]
+        calls[0] = k + 1
+        rc = run(jobs[k % LANES])
         if rc:
             ctx.check(rc)
 

@@ -58,7 +58,7 @@ void slam_destroy(slam_ctx* ctx);
 const char* slam_last_error(const slam_ctx* ctx); /* ctx may be NULL: text of the last slam_create failure */
 /* use the caller's HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it */
 int slam_set_stream(slam_ctx* ctx, void* hip_stream);
-/* Number of internal streams (1..3, default 1) that successive slam_ransac_f_dev calls rotate over.  With more than
+/* Number of internal streams (1..4, default 1) that successive slam_ransac_f_dev calls rotate over.  With more than
  * one, consecutive calls may run concurrently (one call's selection overlaps the next call's solve): they must be
  * independent of each other, use distinct output buffers, and their outputs are ready only after slam_synchronize().
  * Ignored while a caller-supplied stream is set.  No counterpart in the reference (it is single-threaded). */
@@ -100,6 +100,17 @@ int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, int N, cons
 int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                       int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
                       uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all);
+/* A prepared slam_ransac_f_dev call.  The arguments are checked and stored once; slam_job_run enqueues the same work
+ * again, exactly as slam_ransac_f_dev would (including the rotation over the context's internal streams).  For
+ * callers whose per-call argument marshalling is a cost of its own (ctypes spends 2 us on the 15 arguments, as much as
+ * the two kernel launches): frame loops that score the same buffers again and again.  The buffers must stay valid
+ * until the job is destroyed.  No counterpart in the reference. */
+typedef struct slam_job slam_job;
+int slam_ransac_job_create(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
+                           int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
+                           uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all, slam_job** out);
+int slam_job_run(slam_job* job);
+void slam_job_destroy(slam_job* job);
 /* Adaptive termination (the standard RANSAC stopping rule; no counterpart in the reference, which always runs every
  * iteration).  Iterations 0, 1, 2, ... are scored in chunks of `chunk`; after each chunk the number of iterations
  * needed to have drawn, with probability `confidence`, at least one sample of 8 inliers is re-estimated from the best

@@ -37,6 +37,10 @@ SIGNATURES = {
     "slam_eightpoint": (_int, [_vp, _vp, _vp, _int, _vp]),
     "slam_ransac_f": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
     "slam_ransac_f_dev": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "slam_ransac_job_create": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp,
+                                      C.POINTER(_vp)]),
+    "slam_job_run": (_int, [_vp]),
+    "slam_job_destroy": (None, [_vp]),
     "slam_ransac_f_adaptive": (_int, [_vp, _vp, _vp, _int, _int, _u64, _i64, _int, _f64, _f64, _vp, _vp, _vp]),
     "slam_merge_records": (_int, [_vp, _int, _vp]),
     "slam_normalize_points": (_int, [_vp, _vp, _int, _vp, _vp]),

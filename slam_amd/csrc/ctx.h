@@ -26,14 +26,14 @@ struct slam_prof {
     int64_t launches[SLAM_K_COUNT] = {};
 };
 
-#define SLAM_LANES 3  // internal streams that independent RANSAC calls rotate over
+#define SLAM_LANES 4  // internal streams that independent RANSAC calls rotate over
 
 struct slam_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;   // lane 0
     hipStream_t stream = nullptr;       // the context's ordered stream: own_stream, or the caller's (slam_set_stream)
     hipStream_t cur = nullptr;          // stream the launch helper uses right now (stream, or a lane)
-    hipStream_t lane_stream[SLAM_LANES] = {nullptr, nullptr, nullptr};
+    hipStream_t lane_stream[SLAM_LANES] = {};
     unsigned next_lane = 0;
     int lanes_in_use = 1;               // slam_set_concurrency
     bool sampson = false;               // slam_set_scoring
@@ -55,7 +55,7 @@ struct slam_ctx {
     slam_buf flags;     // int32[4] error flags written by kernels
     slam_buf track;     // tracking step: work block + per-hypothesis blocks
     slam_buf batch;     // slam_init_pairs: all pairs' points, planes and per-pair blocks
-    hipEvent_t lane_event[SLAM_LANES + 1] = {nullptr, nullptr, nullptr, nullptr};  // created on first use
+    hipEvent_t lane_event[SLAM_LANES + 1] = {};  // created on first use
     slam_buf match;     // descriptor matching: per-slice candidate keys, staged descriptors and points
     uint64_t raw_seed = 0;
     int64_t raw_it0 = 0, raw_n = 0;

@@ -116,7 +116,7 @@ extern "C" int slam_set_stream(slam_ctx* ctx, void* hip_stream) {
 
 extern "C" int slam_set_concurrency(slam_ctx* ctx, int lanes) {
     if (!ctx) return SLAM_EINVAL;
-    SLAM_REQUIRE(ctx, lanes >= 1 && lanes <= SLAM_LANES, "lanes must be 1..3");
+    SLAM_REQUIRE(ctx, lanes >= 1 && lanes <= SLAM_LANES, "lanes must be 1..4");
     SLAM_TRY(slam_sync_all(ctx));
     ctx->lanes_in_use = lanes;
     ctx->next_lane = 0;
@@ -436,6 +436,49 @@ extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double
     ctx->cur = ctx->stream;
     return rc;
 }
+
+struct slam_job {
+    slam_ctx* ctx;
+    const double *d_p0, *d_p1;
+    int N;
+    const int32_t* d_idx;
+    int sampler;
+    uint64_t seed;
+    int64_t it0;
+    int H;
+    double threshold;
+    double* d_record;
+    uint8_t* d_mask;
+    int32_t* d_counts;
+    double* d_errsums;
+    double* d_F_all;
+};
+
+extern "C" int slam_ransac_job_create(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
+                                      int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
+                                      uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all,
+                                      slam_job** out) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, out != nullptr, "out is NULL");
+    *out = nullptr;
+    SLAM_REQUIRE(ctx, d_p0 && d_p1 && d_record, "points or record pointer is NULL");
+    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
+    SLAM_REQUIRE(ctx, H >= 1 && it0 >= 0, "H < 1 or it0 < 0");
+    SLAM_REQUIRE(ctx, d_idx || sampler == SLAM_SAMPLER_CPYTHON || sampler == SLAM_SAMPLER_COUNTER, "unknown sampler");
+    slam_job* j = new (std::nothrow) slam_job{ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record,
+                                              d_mask, d_counts, d_errsums, d_F_all};
+    if (!j) return SLAM_ENOMEM;
+    *out = j;
+    return SLAM_OK;
+}
+
+extern "C" int slam_job_run(slam_job* j) {
+    if (!j) return SLAM_EINVAL;
+    return slam_ransac_f_dev(j->ctx, j->d_p0, j->d_p1, j->N, j->d_idx, j->sampler, j->seed, j->it0, j->H, j->threshold,
+                             j->d_record, j->d_mask, j->d_counts, j->d_errsums, j->d_F_all);
+}
+
+extern "C" void slam_job_destroy(slam_job* j) { delete j; }
 
 // stage two (N,2) point arrays contiguously in ctx->pts; returns device pointers
 static int stage_points(slam_ctx* ctx, const double* p0, const double* p1, int64_t N, double** d0, double** d1) {

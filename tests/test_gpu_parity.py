@@ -339,8 +339,8 @@ def test_whole_pair_matches_reference(ctx, name):
 
 # ---------------------------------------------------------------------------------------------- device-resident API
 def test_device_calls_in_flight_match_serial(ctx):
-    """slam_ransac_f_dev on device-resident matches: with three calls in flight on the context's internal streams
-    every call returns bit for bit what it returns alone."""
+    """slam_ransac_f_dev on device-resident matches: with several calls in flight on the context's internal streams
+    every call returns bit for bit what it returns alone (four streams here, the maximum)."""
     import torch
     dev = torch.device("cuda", ctx.device)
     lib = ctx.lib
@@ -365,7 +365,7 @@ def test_device_calls_in_flight_match_serial(ctx):
 
     try:
         serial = run(1)
-        overlapped = run(3)
+        overlapped = run(4)
     finally:
         ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
     for a, b in zip(serial[0], overlapped[0]):
@@ -540,3 +540,34 @@ def test_config4_hundred_pairs_in_one_call(ctx):
         pose, X, counts, w = co.pose_from_E(E, K, d["pts0"], d["pts1"], threads=8)
         assert np.allclose(b["pose"], pose, atol=1e-7)
         assert point_err(b["X"], X) < X_TOL
+
+
+def test_prepared_job_equals_direct_call(ctx):
+    """slam_job_run enqueues exactly what slam_ransac_f_dev enqueues for the stored arguments."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    d = synth.make_pair(3000, 0.3, seed=77)
+    n0, _ = so.normalize_points(d["pts0"])
+    n1, _ = so.normalize_points(d["pts1"])
+    p0, p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+    rec_a = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    rec_b = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    mask_a = torch.zeros(3000, dtype=torch.uint8, device=dev)
+    mask_b = torch.zeros(3000, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    lib = ctx.lib
+    ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), 3000, None, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE,
+                                    0, 700, 0.005, rec_a.data_ptr(), mask_a.data_ptr(), None, None, None))
+    job = C.c_void_p()
+    ctx.check(lib.slam_ransac_job_create(ctx.handle, p0.data_ptr(), p1.data_ptr(), 3000, None, _lib.SAMPLER_CPYTHON,
+                                         _lib.SEED_BASE, 0, 700, 0.005, rec_b.data_ptr(), mask_b.data_ptr(), None, None, None,
+                                         C.byref(job)))
+    for _ in range(3):
+        ctx.check(lib.slam_job_run(job))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    lib.slam_job_destroy(job)
+    assert torch.equal(rec_a, rec_b) and torch.equal(mask_a, mask_b)
+    bad = C.c_void_p()
+    assert lib.slam_ransac_job_create(ctx.handle, p0.data_ptr(), p1.data_ptr(), 7, None, 0, 0, 0, 10, 0.005, rec_b.data_ptr(),
+                                      None, None, None, None, C.byref(bad)) == -1 and not bad.value

@@ -17,7 +17,7 @@ d = synth.make_pair(4096, 0.3, seed=2)
 n0, _ = so.normalize_points(d["pts0"])
 n1, _ = so.normalize_points(d["pts1"])
 p0, p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
-recs = [torch.zeros(12, dtype=torch.float64, device=dev) for _ in range(3)]
+recs = [torch.zeros(12, dtype=torch.float64, device=dev) for _ in range(4)]
 torch.cuda.synchronize()
 lib.slam_set_concurrency(ctx.handle, int(os.environ.get("LANES", "3")))
 fn, h = lib.slam_ransac_f_dev, ctx.handle
@@ -27,7 +27,7 @@ K = 4000
 for rep in range(3):
     t0 = time.perf_counter()
     for i in range(K):
-        fn(h, a0, a1, 4096, None, 0, 0x1337BEEF, 0, 2048, 0.005, rp[i % 3], None, None, None, None)
+        fn(h, a0, a1, 4096, None, 0, 0x1337BEEF, 0, 2048, 0.005, rp[i % 4], None, None, None, None)
     t1 = time.perf_counter()
     lib.slam_synchronize(h)
     t2 = time.perf_counter()

@@ -56,6 +56,7 @@ struct slam_ctx {
     slam_buf track;     // tracking step: work block + per-hypothesis blocks
     slam_buf batch;     // slam_init_pairs: all pairs' points, planes and per-pair blocks
     hipEvent_t lane_event[SLAM_LANES + 1] = {};  // created on first use
+    slam_buf select_parts[SLAM_LANES];  // range winners of the two-stage selection (large H), per internal stream
     slam_buf match;     // descriptor matching: per-slice candidate keys, staged descriptors and points
     uint64_t raw_seed = 0;
     int64_t raw_it0 = 0, raw_n = 0;

@@ -585,8 +585,37 @@ __device__ __forceinline__ Best wave_best(Best b) {
     return b;
 }
 
+// first stage for large H: every workgroup reduces a contiguous range of SLAM_SELECT_SPAN hypotheses to its best
+// (same order relation, so the two stages together equal one pass); k_select then runs on the range winners
+#define SLAM_SELECT_SPAN 8192
+__global__ __launch_bounds__(1024) void k_select_partial(const int32_t* __restrict__ counts,
+                                                         const double* __restrict__ errsums, int H,
+                                                         int32_t* __restrict__ p_counts, double* __restrict__ p_errsums,
+                                                         int32_t* __restrict__ p_index) {
+    __shared__ Best s_best[16];
+    const int tid = threadIdx.x;
+    const int lo = blockIdx.x * SLAM_SELECT_SPAN, hi = min(H, lo + SLAM_SELECT_SPAN);
+    Best b{-1, 0x7fffffff, 0.0};
+    for (int h = lo + tid; h < hi; h += 1024) {
+        const Best c{counts[h], h, errsums[h]};
+        if (better(c, b)) b = c;
+    }
+    b = wave_best(b);
+    if ((tid & 63) == 0) s_best[tid >> 6] = b;
+    __syncthreads();
+    if (tid == 0) {
+        Best w = s_best[0];
+        for (int q = 1; q < 16; ++q)
+            if (better(s_best[q], w)) w = s_best[q];
+        p_counts[blockIdx.x] = w.count;
+        p_errsums[blockIdx.x] = w.errsum;
+        p_index[blockIdx.x] = w.index;
+    }
+}
+
 template <bool SAMPSON>
 __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
+                                                 const int32_t* __restrict__ index_of,  // NULL: entry h is hypothesis h
                                                  const double* __restrict__ Fall, int H, int64_t it0,
                                                  const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
                                                  double rcut, double* __restrict__ record, uint8_t* __restrict__ mask) {
@@ -597,7 +626,7 @@ __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ cou
     const double2 a_first = p0[i0], b_first = p1[i0];
     Best b{-1, 0x7fffffff, 0.0};
     for (int h = tid; h < H; h += 1024) {
-        const Best c{counts[h], h, errsums[h]};
+        const Best c{counts[h], index_of ? index_of[h] : h, errsums[h]};
         if (better(c, b)) b = c;
     }
     b = wave_best(b);

@@ -88,6 +88,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
         if (b->p) (void)hipFree(b->p);
     for (int l = 0; l < SLAM_LANES; ++l) {
         if (ctx->lane_F[l].p) (void)hipFree(ctx->lane_F[l].p);
+        if (ctx->select_parts[l].p) (void)hipFree(ctx->select_parts[l].p);
         if (ctx->lane_counts[l].p) (void)hipFree(ctx->lane_counts[l].p);
         if (ctx->lane_errsums[l].p) (void)hipFree(ctx->lane_errsums[l].p);
         if (l > 0 && ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
@@ -405,12 +406,31 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     } else {
         SLAM_TRY(launch_ransac<SLAM_SAMPLER_COUNTER>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
     }
+    // large H: a first stage reduces ranges of SLAM_SELECT_SPAN hypotheses in parallel
+    const int32_t* sel_counts = d_counts;
+    const double* sel_errsums = d_errsums;
+    const int32_t* sel_index = nullptr;
+    int sel_H = H;
+    if (H > 4 * SLAM_SELECT_SPAN) {
+        const int parts = (H + SLAM_SELECT_SPAN - 1) / SLAM_SELECT_SPAN;
+        int lane = 0;  // calls in flight on different internal streams must not share the table
+        for (int l = 1; l < SLAM_LANES; ++l)
+            if (ctx->cur == ctx->lane_stream[l]) lane = l;
+        slam_buf& table = ctx->select_parts[lane];
+        SLAM_TRY(slam_reserve(ctx, table, (size_t)parts * 16));
+        int32_t* pc = (int32_t*)table.p;
+        int32_t* pi = pc + parts;
+        double* pe = (double*)((char*)table.p + (size_t)parts * 8);
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select_partial, dim3(parts), dim3(1024), 0, (const int32_t*)d_counts,
+                             (const double*)d_errsums, H, pc, pe, pi));
+        sel_counts = pc; sel_errsums = pe; sel_index = pi; sel_H = parts;
+    }
     if (ctx->sampson)
-        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<true>, dim3(1), dim3(1024), 0, (const int32_t*)d_counts,
-                             (const double*)d_errsums, (const double*)d_F_all, H, it0, p0, p1, N, thr, d_record, d_mask));
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<true>, dim3(1), dim3(1024), 0, sel_counts, sel_errsums, sel_index,
+                             (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask));
     else
-        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1), dim3(1024), 0, (const int32_t*)d_counts,
-                             (const double*)d_errsums, (const double*)d_F_all, H, it0, p0, p1, N, thr, d_record, d_mask));
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1), dim3(1024), 0, sel_counts, sel_errsums, sel_index,
+                             (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask));
     return SLAM_OK;
 }
 
@@ -585,11 +605,13 @@ extern "C" int slam_ransac_f_adaptive(slam_ctx* ctx, const double* p0, const dou
         const double2 *q0 = (const double2*)d0, *q1 = (const double2*)d1;
         if (ctx->sampson)
             SLAM_TRY(slam_launch(ctx, -1, k_select<true>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
-                                 (const double*)ctx->errsums.p, (const double*)dF, 1, (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
+                                 (const double*)ctx->errsums.p, (const int32_t*)nullptr, (const double*)dF, 1,
+                                 (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
                                  cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p));
         else
             SLAM_TRY(slam_launch(ctx, -1, k_select<false>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
-                                 (const double*)ctx->errsums.p, (const double*)dF, 1, (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
+                                 (const double*)ctx->errsums.p, (const int32_t*)nullptr, (const double*)dF, 1,
+                                 (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
                                  cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p));
         SLAM_HIP(ctx, hipMemcpyAsync(mask, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
         SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));

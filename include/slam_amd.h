@@ -218,6 +218,17 @@ int slam_match_points_dev(slam_ctx* ctx, const uint8_t* d_des0, const double* d_
                           const double* d_pts1, int n1, double* d_matched0, double* d_matched1, int32_t* d_n_matched,
                           int32_t* d_index, int32_t* d_distance);
 
+/* ---- a frame pair from features: custom_slam.py:105-115 after the ORB calls ------------------------- */
+/* Keypoints and packed descriptors of two images in; 2-NN matching, ratio test, then the whole-pair pipeline of
+ * slam_init_pair on the kept matches, which never leave the device in between (only their count comes back, to size
+ * the launches).  matched0/matched1: room for (n0,2) each, *n_matched rows written; the per-match outputs X
+ * (n0 x 3 room) and good (n0 room) have *n_matched rows.  Returns SLAM_EINVAL (after writing the matches) when fewer
+ * than 8 matches survive, where the reference's RANSAC asserts. */
+int slam_frame_pair(slam_ctx* ctx, const uint8_t* des0, const double* pts0, int n0, const uint8_t* des1,
+                    const double* pts1, int n1, const double* K, int iterations, double* matched0, double* matched1,
+                    int32_t* n_matched, double* F, double* E, double* pose, double* X, uint8_t* good, double* record,
+                    int32_t* counts4, int32_t* winner);
+
 /* ---- kernel timing for benchmarks ---------------------------------------------------------------- */
 #define SLAM_K_SOLVE 0
 #define SLAM_K_SCORE 1

@@ -59,6 +59,8 @@ SIGNATURES = {
     "slam_match_knn": (_int, [_vp, _vp, _int, _vp, _int, _int, _vp, _vp]),
     "slam_match_points": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "slam_match_points_dev": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    "slam_frame_pair": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp]),
     "slam_profile_enable": (_int, [_vp, _int]),
     "slam_profile_read": (_int, [_vp, _int, C.POINTER(_f64), C.POINTER(_i64)]),
     "slam_profile_reset": (_int, [_vp]),

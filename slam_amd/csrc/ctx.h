@@ -41,6 +41,7 @@ struct slam_ctx {
 
     // device scratch (grown on demand, never shrunk)
     slam_buf pts;       // staged (N,2)+(N,2) points of the host entry points
+    slam_buf norm;      // normalised copies of a pair's matches (pair pipeline)
     slam_buf idx;       // H*8 int32
     slam_buf F;         // H*9 f64        } lane 0's hypothesis scratch
     slam_buf counts;    // H int32        }

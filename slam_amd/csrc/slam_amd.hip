@@ -82,7 +82,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)slam_sync_all(ctx);
-    slam_buf* bufs[] = {&ctx->pts, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
+    slam_buf* bufs[] = {&ctx->pts, &ctx->norm, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
                         &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track, &ctx->match, &ctx->batch};
     for (slam_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -805,26 +805,27 @@ extern "C" int slam_pose_from_E(slam_ctx* ctx, const double* E, const double* K,
 // ================================================================================================
 // whole pair
 // ================================================================================================
-extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* pts1, int N, const double* K,
-                              int iterations, double* F, double* E, double* pose, double* X, uint8_t* good,
-                              double* record, int32_t* counts4, int32_t* winner) {
-    if (!ctx) return SLAM_EINVAL;
-    SLAM_REQUIRE(ctx, pts0 && pts1 && K, "NULL pointer");
-    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
-    SLAM_REQUIRE(ctx, iterations >= 1, "iterations < 1");
-    SLAM_HIP(ctx, hipSetDevice(ctx->device));
-    struct KeepScoring {  // the pair pipeline always scores with the reference's residual
-        slam_ctx* c; bool was;
-        explicit KeepScoring(slam_ctx* c_) : c(c_), was(c_->sampson) { c->sampson = false; }
-        ~KeepScoring() { c->sampson = was; }
-    } keep_scoring(ctx);
+// the pair pipeline always scores with the reference's residual, whatever slam_set_scoring says
+namespace {
+struct KeepScoring {
+    slam_ctx* c;
+    bool was;
+    explicit KeepScoring(slam_ctx* c_) : c(c_), was(c_->sampson) { c->sampson = false; }
+    ~KeepScoring() { c->sampson = was; }
+};
+}  // namespace
+
+// Whole-pair pipeline on matches that are already on the device (r0, r1: pixel coordinates, (N,2) each): normalise,
+// RANSAC, denormalise, F -> E, four candidate triangulations, selection, z > 0 flags; then the small results and the
+// requested arrays come back and the stream is synchronised.
+static int init_pair_on_device(slam_ctx* ctx, const double* r0, const double* r1, int N, const double* K, int iterations,
+                               double* F, double* E, double* pose, double* X, uint8_t* good, double* record,
+                               int32_t* counts4, int32_t* winner) {
+    KeepScoring keep_scoring(ctx);
     const int H = (int)slam_num_hypotheses(N, iterations);
     const size_t bytes = (size_t)N * 2 * sizeof(double), stride = (bytes + 63) & ~(size_t)63;
-    // pts: raw0 | raw1 | norm0 | norm1
-    SLAM_TRY(slam_reserve(ctx, ctx->pts, 4 * stride + 64));
-    char* base = (char*)ctx->pts.p;
-    double *r0 = (double*)base, *r1 = (double*)(base + stride), *n0 = (double*)(base + 2 * stride),
-           *n1 = (double*)(base + 3 * stride);
+    SLAM_TRY(slam_reserve(ctx, ctx->norm, 2 * stride + 64));
+    double *n0 = (double*)ctx->norm.p, *n1 = (double*)((char*)ctx->norm.p + stride);
     SLAM_TRY(slam_reserve(ctx, ctx->X, (size_t)N * 3 * sizeof(double)));
     SLAM_TRY(slam_reserve(ctx, ctx->mask, (size_t)N));
     SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
@@ -838,8 +839,6 @@ extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* p
     double* d_pose = small + 710;
     int32_t* d_winner = (int32_t*)(small + 730);
     double* d_record = (double*)ctx->record.p;
-    SLAM_HIP(ctx, hipMemcpyAsync(r0, pts0, bytes, hipMemcpyHostToDevice, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(r1, pts1, bytes, hipMemcpyHostToDevice, ctx->stream));
     Mat3x2 kk;
     memcpy(kk.A, K, sizeof kk.A);
     memset(kk.B, 0, sizeof kk.B);
@@ -871,6 +870,19 @@ extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* p
     if (counts4) for (int i = 0; i < 4; ++i) counts4[i] = (int32_t)c[i];
     if (winner) *winner = *(const int32_t*)(hs + 60);
     return SLAM_OK;
+}
+
+extern "C" int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* pts1, int N, const double* K,
+                              int iterations, double* F, double* E, double* pose, double* X, uint8_t* good,
+                              double* record, int32_t* counts4, int32_t* winner) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, pts0 && pts1 && K, "NULL pointer");
+    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
+    SLAM_REQUIRE(ctx, iterations >= 1, "iterations < 1");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    double *r0, *r1;
+    SLAM_TRY(stage_points(ctx, pts0, pts1, N, &r0, &r1));
+    return init_pair_on_device(ctx, r0, r1, N, K, iterations, F, E, pose, X, good, record, counts4, winner);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1235,6 +1247,57 @@ extern "C" int slam_match_knn(slam_ctx* ctx, const uint8_t* des0, int n0, const 
     SLAM_TRY(match_host(ctx, des0, nullptr, n0, des1, nullptr, n1, nullptr, nullptr, nullptr, i2.data(), d2.data()));
     for (int q = 0; q < n0; ++q) { index[q] = i2[2 * (size_t)q]; distance[q] = d2[2 * (size_t)q]; }
     return SLAM_OK;
+}
+
+// ================================================================================================
+// a frame pair from keypoints and descriptors
+// ================================================================================================
+extern "C" int slam_frame_pair(slam_ctx* ctx, const uint8_t* des0, const double* pts0, int n0, const uint8_t* des1,
+                               const double* pts1, int n1, const double* K, int iterations, double* matched0,
+                               double* matched1, int32_t* n_matched, double* F, double* E, double* pose, double* X,
+                               uint8_t* good, double* record, int32_t* counts4, int32_t* winner) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, des0 && des1 && pts0 && pts1 && K && matched0 && matched1 && n_matched, "NULL pointer");
+    SLAM_MATCH_ARGS_OK(ctx, n0, n1);
+    SLAM_REQUIRE(ctx, iterations >= 1, "iterations < 1");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    // match buffer: partial keys | des0 | des1 | pts0 | pts1 | matched0 | matched1 | count
+    const int slices = match_slices(n0, n1);
+    const size_t b_part = align256((size_t)n0 * slices * 2 * sizeof(uint32_t));
+    const size_t b_d0 = align256((size_t)n0 * 32), b_d1 = align256((size_t)n1 * 32);
+    const size_t b_p0 = align256((size_t)n0 * 16), b_p1 = align256((size_t)n1 * 16), b_m = align256((size_t)n0 * 16);
+    SLAM_TRY(slam_reserve(ctx, ctx->match, b_part + b_d0 + b_d1 + b_p0 + b_p1 + 2 * b_m + 256));
+    char* at = (char*)ctx->match.p;
+    auto take = [&](size_t bytes) { char* p = at; at += bytes; return p; };
+    uint32_t* d_part = (uint32_t*)take(b_part);
+    uint8_t* d_d0 = (uint8_t*)take(b_d0);
+    uint8_t* d_d1 = (uint8_t*)take(b_d1);
+    double* d_p0 = (double*)take(b_p0);
+    double* d_p1 = (double*)take(b_p1);
+    double* d_m0 = (double*)take(b_m);
+    double* d_m1 = (double*)take(b_m);
+    int32_t* d_n = (int32_t*)take(256);
+    SLAM_HIP(ctx, hipMemcpyAsync(d_d0, des0, (size_t)n0 * 32, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(d_d1, des1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(d_p0, pts0, (size_t)n0 * 16, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(d_p1, pts1, (size_t)n1 * 16, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_TRY(match_enqueue(ctx, d_d0, d_p0, n0, d_d1, d_p1, n1, slices, d_part, d_m0, d_m1, d_n, nullptr, nullptr));
+    // the number of matches sizes every later launch: the one value that has to come back in the middle
+    int32_t* h_n = (int32_t*)(ctx->h_small + 128);
+    SLAM_HIP(ctx, hipMemcpyAsync(h_n, d_n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int M = *h_n;
+    *n_matched = M;
+    if (M > 0) {
+        SLAM_HIP(ctx, hipMemcpyAsync(matched0, d_m0, (size_t)M * 16, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(matched1, d_m1, (size_t)M * 16, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (M < 8) {  // the reference asserts here (src/epipolar.py:60)
+        SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        snprintf(ctx->err, sizeof ctx->err, "invalid argument: only %d matches pass the ratio test, 8 are needed", M);
+        return SLAM_EINVAL;
+    }
+    return init_pair_on_device(ctx, d_m0, d_m1, M, K, iterations, F, E, pose, X, good, record, counts4, winner);
 }
 
 #ifdef SLAM_STAMPS

@@ -83,6 +83,34 @@ def initialise_pairs(pairs, intrinsic_camera_matrix, iterations=1000, ctx=None):
     return out
 
 
+def frame_pair(img0_pts, img0_des, img1_pts, img1_des, intrinsic_camera_matrix, iterations=1000, ctx=None):
+    """Keypoints and descriptors of two images -> matches (2-NN, ratio test) -> whole two-view initialisation, in one
+    library call; the matches stay on the device between the two stages   (reference: custom_slam.py:56-82 after the
+    ORB calls, then :96-115).  Returns the dict of initialise_pair plus the matched point lists."""
+    from .matching import pack_descriptors
+    p0 = f64(np.asarray(img0_pts)).reshape(-1, 2)
+    p1 = f64(np.asarray(img1_pts)).reshape(-1, 2)
+    d0, d1 = pack_descriptors(img0_des), pack_descriptors(img1_des)
+    assert len(p0) == len(d0) and len(p1) == len(d1)
+    K = f64(intrinsic_camera_matrix)
+    n0 = len(p0)
+    m0, m1 = np.empty((n0, 2)), np.empty((n0, 2))
+    n = np.zeros(1, dtype=np.int32)
+    F, E, pose = np.empty((3, 3)), np.empty((3, 3)), np.empty((4, 4))
+    X = np.empty((n0, 3))
+    good = np.empty(n0, dtype=np.uint8)
+    record = np.empty(REC_LEN)
+    counts4 = np.empty(4, dtype=np.int32)
+    winner = np.empty(1, dtype=np.int32)
+    ctx = ctx or _lib.default_context()
+    ctx.check(ctx.lib.slam_frame_pair(ctx.handle, ptr(d0), ptr(p0), n0, ptr(d1), ptr(p1), len(p1), ptr(K), int(iterations),
+                                      ptr(m0), ptr(m1), ptr(n), ptr(F), ptr(E), ptr(pose), ptr(X), ptr(good), ptr(record),
+                                      ptr(counts4), ptr(winner)))
+    k = int(n[0])
+    return dict(matched0=m0[:k].copy(), matched1=m1[:k].copy(), F=F, E=E, pose=pose, X=X[:k].copy(),
+                mask=good[:k].astype(bool), record=record, counts=counts4, winner=int(winner[0]))
+
+
 def find_pose_and_triangulated_points(img0_points, img1_points, intrinsic_camera_matrix, iterations=1000):
     """The reference's return tuple (custom_slam.py:105-115), starting from matches instead of images."""
     r = initialise_pair(img0_points, img1_points, intrinsic_camera_matrix, iterations)

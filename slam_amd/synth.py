@@ -148,3 +148,30 @@ def make_track(n_known, n_matches, outlier_frac=0.2, seed=0, K=KITTI_K, size=KIT
     return {"previous_pose": pose_of(R1, t1), "next_pose": pose_of(R2, t2), "prev_known": prev_known,
             "next_known": next_known, "X_known": X_known, "prev_all": prev, "next_all": nxt,
             "inlier": inlier, "K": np.array(K)}
+
+
+def make_feature_pair(n_true, n_clutter=0, flip_bits=20, seed=0, outlier_frac=0.0, **kw):
+    """Keypoints with 256-bit descriptors for two views of one scene: ``n_true`` scene points seen in both images
+    (descriptor of the second view = the first with ``flip_bits`` random bits flipped), ``n_clutter`` unrelated
+    keypoints per image, image-1 keypoints in shuffled order.  Returns the dict of make_pair plus kp0, des0, kp1, des1
+    (descriptors packed, 32 bytes) and ``truth``: for every image-0 keypoint the index of its image-1 partner or -1."""
+    d = make_pair(n_true, outlier_frac, seed, **kw)
+    rng = np.random.default_rng(seed + 7919)
+    w, h = kw.get("size", KITTI_SIZE)
+    bits0 = rng.integers(0, 2, (n_true, 256), dtype=np.uint8)
+    bits1 = bits0.copy()
+    for i in range(n_true):
+        bits1[i, rng.choice(256, flip_bits, replace=False)] ^= 1
+    c0 = rng.integers(0, 2, (n_clutter, 256), dtype=np.uint8)
+    c1 = rng.integers(0, 2, (n_clutter, 256), dtype=np.uint8)
+    kp0 = np.vstack([d["pts0"], np.column_stack([rng.uniform(0, w, n_clutter), rng.uniform(0, h, n_clutter)])])
+    kp1 = np.vstack([d["pts1"], np.column_stack([rng.uniform(0, w, n_clutter), rng.uniform(0, h, n_clutter)])])
+    des0 = np.packbits(np.vstack([bits0, c0]), axis=1)
+    des1 = np.packbits(np.vstack([bits1, c1]), axis=1)
+    order0 = rng.permutation(n_true + n_clutter)
+    order1 = rng.permutation(n_true + n_clutter)
+    where1 = np.empty_like(order1)
+    where1[order1] = np.arange(len(order1))
+    truth = np.where(order0 < n_true, where1[np.minimum(order0, n_true + n_clutter - 1)], -1)
+    d.update(kp0=kp0[order0], des0=des0[order0], kp1=kp1[order1], des1=des1[order1], truth=truth)
+    return d

@@ -107,3 +107,39 @@ def test_device_entry_point(ctx):
     k = int(n.item())
     assert k == len(h0)
     assert np.array_equal(m0[:k].cpu().numpy(), h0) and np.array_equal(m1[:k].cpu().numpy(), h1)
+
+
+def test_frame_pair_equals_its_two_stages(ctx):
+    """slam_frame_pair (descriptors in, pose and points out, matches kept on the device) returns bit for bit what
+    matching followed by the whole-pair entry point returns, and what the CPU restatements give within tolerance."""
+    from conftest import fix_sign_scale, rel_err
+    from slam_amd import pipeline, synth
+    from test_gpu_parity import point_err
+    d = synth.make_feature_pair(1500, n_clutter=700, seed=21)
+    r = pipeline.frame_pair(d["kp0"], d["des0"], d["kp1"], d["des1"], d["K"], iterations=500, ctx=ctx)
+    m0, m1 = matching.matches_between_keypoints(d["kp0"], d["des0"], d["kp1"], d["des1"], ctx)
+    assert np.array_equal(r["matched0"], m0) and np.array_equal(r["matched1"], m1)
+    assert 1450 <= len(m0) <= 1500                         # the scene points match, the clutter fails the ratio test
+    two = pipeline.initialise_pair(m0, m1, d["K"], iterations=500, ctx=ctx)
+    for key in ("F", "E", "pose", "X", "mask", "record", "counts"):
+        assert np.array_equal(np.asarray(r[key]), np.asarray(two[key])), key
+    # against the restatements
+    wi, wd = so.match_knn_brute_force(d["des0"], d["des1"], 2)
+    w0, w1, _ = so.select_matches(d["kp0"], d["kp1"], wi, wd)
+    assert np.array_equal(w0, m0) and np.array_equal(w1, m1)
+    ref = so.initialise_pair(w0, w1, d["K"], iterations=500)
+    assert int(r["record"][_lib.REC_INDEX]) == ref["ransac"]["best_index"]
+    assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(ref["F"])) < 1e-6
+    assert np.allclose(r["pose"], ref["pose"], atol=1e-7)
+    assert point_err(r["X"], ref["X"]) < 1e-5
+    # and the motion is roughly the scene's (the 8-point estimate without refinement is only good to a degree or two)
+    R = r["pose"][:3, :3].T
+    cos = (np.trace(R.T @ d["R"]) - 1) / 2
+    assert np.degrees(np.arccos(np.clip(cos, -1, 1))) < 5.0
+
+
+def test_frame_pair_with_too_few_matches(ctx):
+    from slam_amd import pipeline, synth
+    d = synth.make_feature_pair(5, n_clutter=200, seed=22)
+    with pytest.raises(AssertionError):
+        pipeline.frame_pair(d["kp0"], d["des0"], d["kp1"], d["des1"], d["K"], ctx=ctx)

@@ -485,13 +485,14 @@ __global__ __launch_bounds__(64 * WAVES, 32 / WAVES) void k_score(const double2*
     score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
 }
 
-// K1+K2 fused for small H.  A workgroup owns WAVES hypotheses:
-//   1. every wave draws the index set of one hypothesis (wave-parallel draw) and starts loading its share of the
-//      first chunk of matches;
-//   2. lanes 0..WAVES-1 of wave 0 solve one hypothesis each (the same single-lane arithmetic as k_solve, so F is
-//      bit-identical to the split path); the other waves wait with their matches already in registers;
+// K1+K2 fused for small H.  A workgroup of eight waves owns eight hypotheses:
+//   1. wave w draws the index set of hypothesis w (wave-parallel draw);
+//   2. wave 0 solves the eight hypotheses, eight lanes each (the arithmetic of k_solve's one-lane solve, spread over
+//      the lanes that own the columns, so F is bit-identical to the split path); the other waves request their
+//      matches of the first chunk meanwhile, wave 0 after its solve;
 //   3. the workgroup scores its hypotheses.
-// One launch and no round trip of F through memory between solve and score.
+// One launch, no round trip of F through memory between solve and score, and at most 128 registers, so that two
+// workgroups fit a CU and one of them can score while the other one solves.
 // workgroup barrier that waits for this wave's LDS traffic only: global loads stay in flight across it
 __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -297,34 +297,37 @@ __global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, 
             else if (c == r) partner = 11;
             else { partner = 2 * r - c; partner += partner < 0 ? 11 : 0; partner -= partner >= 11 ? 11 : 0; }
             const int src = base + partner;
-            double pa[12], pv[12];
+            double pa[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) pa[i] = __shfl(a[i], src, 64);
+            // squared norms and inner product of the pair; both lanes of a pair add the same numbers in the same order
+            double own = 0.0, other = 0.0, spq = 0.0;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
-                pa[i] = __shfl(a[i], src, 64);
-                pv[i] = __shfl(v[i], src, 64);
+                own = fma(a[i], a[i], own);
+                other = fma(pa[i], pa[i], other);
+                spq = fma(a[i], pa[i], spq);
             }
-            // the pair in (lower column, higher column) order, the same on both of its lanes
+            // (lower column, higher column) order, the same on both lanes
             const bool low = c < partner;
-            double sp = 0.0, sq = 0.0, spq = 0.0;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const double x = low ? a[i] : pa[i], y = low ? pa[i] : a[i];
-                sp = fma(x, x, sp);
-                sq = fma(y, y, sq);
-                spq = fma(x, y, spq);
-            }
+            const double sp = low ? own : other, sq = low ? other : own;
             const bool go = c != partner && sp > floor2 && sq > floor2 && spq * spq > 1e-30 * (sp * sq);
-            double cs, sn;
-            jacobi_angle(sp, sq, spq, cs, sn);
-            cs = go ? cs : 1.0;
-            sn = go ? sn : 0.0;
             rotated |= go;
-            // lower column: cs x - sn y ; higher column: sn x + cs y
-            const double mine = cs, other = low ? -sn : sn;
+            if (__any(go)) {  // wave-uniform: a round in which nothing rotates costs the exchange of one column only
+                double pv[12];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                a[i] = fma(mine, a[i], other * pa[i]);
-                v[i] = fma(mine, v[i], other * pv[i]);
+                for (int i = 0; i < 12; ++i) pv[i] = __shfl(v[i], src, 64);
+                double cs, sn;
+                jacobi_angle(sp, sq, spq, cs, sn);
+                cs = go ? cs : 1.0;
+                sn = go ? sn : 0.0;
+                // lower column: cs x - sn y ; higher column: sn x + cs y
+                const double mine = cs, theirs = low ? -sn : sn;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    a[i] = fma(mine, a[i], theirs * pa[i]);
+                    v[i] = fma(mine, v[i], theirs * pv[i]);
+                }
             }
         }
         if (!__any(rotated)) break;

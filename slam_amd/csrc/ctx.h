@@ -63,7 +63,7 @@ struct slam_ctx {
     int64_t raw_it0 = 0, raw_n = 0;
 
     // pinned host staging for small results
-    double* h_small = nullptr;  // 256 doubles
+    double* h_small = nullptr;  // 1024 doubles
     int32_t* h_flags = nullptr;
 
     bool profiling = false;

@@ -354,6 +354,65 @@ __global__ __launch_bounds__(1024) void k_normalize(const double2* __restrict__ 
     }
 }
 
+// both images of a pair in one launch: workgroup 0 normalises pa into outa / Ta, workgroup 1 pb into outb / Tb
+__global__ __launch_bounds__(1024) void k_normalize_pair(const double2* __restrict__ pa, const double2* __restrict__ pb,
+                                                         int N, double2* __restrict__ outa, double2* __restrict__ outb,
+                                                         double* __restrict__ Ta, double* __restrict__ Tb) {
+    __shared__ double s_red[16];
+    const bool second = blockIdx.x != 0;
+    const double2* __restrict__ p = second ? pb : pa;
+    double2* __restrict__ out = second ? outb : outa;
+    double* __restrict__ T = second ? Tb : Ta;
+    const int tid = threadIdx.x;
+    double sx = 0.0, sy = 0.0;
+    for (int i = tid; i < N; i += 1024) { const double2 v = p[i]; sx += v.x; sy += v.y; }
+    const double ax = block_sum_1024(sx, s_red) / (double)N;
+    const double ay = block_sum_1024(sy, s_red) / (double)N;
+    double sd = 0.0;
+    for (int i = tid; i < N; i += 1024) {
+        const double2 v = p[i];
+        const double dx = v.x - ax, dy = v.y - ay;
+        sd += sqrt(dx * dx + dy * dy);
+    }
+    const double s = (block_sum_1024(sd, s_red) / (double)N) / sqrt(2.0);
+    for (int i = tid; i < N; i += 1024) {
+        const double2 v = p[i];
+        out[i] = make_double2((v.x - ax) / s, (v.y - ay) / s);
+    }
+    if (tid == 0) {
+        T[0] = s;   T[1] = 0.0; T[2] = -1.0 * s * ax;
+        T[3] = 0.0; T[4] = s;   T[5] = -1.0 * s * ay;
+        T[6] = 0.0; T[7] = 0.0; T[8] = 1.0;
+    }
+}
+
+// selection and emission in one launch (pair pipelines): every workgroup finds the winner from the four counts, copies
+// its share of the winner's plane and flags X_z > 0; workgroup 0 also writes the pose and the winner's position
+__global__ __launch_bounds__(256) void k_select_emit(const double* __restrict__ pw,
+                                                     const unsigned long long* __restrict__ counts4,
+                                                     const double* __restrict__ X4, int64_t N, double* __restrict__ pose,
+                                                     int32_t* __restrict__ winner, double* __restrict__ X,
+                                                     uint8_t* __restrict__ good) {
+    long long best = -1;
+    int w = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const long long n = (long long)counts4[c];
+        if (n > best) { best = n; w = c; }  // strict: the first maximum   (reference: src/epipolar.py:129-133)
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) *winner = w;
+        if (threadIdx.x < 16) pose[threadIdx.x] = pw[PW_CAND + w * PW_CAND_LEN + PW_CAND_POSE + threadIdx.x];
+    }
+    const double* src = X4 + (size_t)w * (size_t)N * 3;
+    const int64_t total = N * 3;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const double v = src[e];
+        X[e] = v;
+        if (good && (e % 3) == 2) good[e / 3] = v > 0.0 ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Over-determined eight-point solve, M > 8 rows   (reference: src/epipolar.py:37-51 with len(points) > 8)
 // The least right singular vector of the M x 9 design matrix equals that of its 9 x 9 triangular factor R:

@@ -59,7 +59,7 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     for (int l = 1; l < SLAM_LANES; ++l)
         if ((e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking)) != hipSuccess)
             return fail("hipStreamCreate", e);
-    if ((e = hipHostMalloc((void**)&ctx->h_small, 256 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void**)&ctx->h_small, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
         return fail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&ctx->h_flags, 16 * sizeof(int32_t), hipHostMallocDefault)) != hipSuccess)
         return fail("hipHostMalloc", e);
@@ -838,37 +838,32 @@ static int init_pair_on_device(slam_ctx* ctx, const double* r0, const double* r1
     unsigned long long* d_counts4 = (unsigned long long*)(small + 700);
     double* d_pose = small + 710;
     int32_t* d_winner = (int32_t*)(small + 730);
-    double* d_record = (double*)ctx->record.p;
+    double* d_record = small + 740;  // with the other small results, so that one copy brings all of them back
     Mat3x2 kk;
     memcpy(kk.A, K, sizeof kk.A);
     memset(kk.B, 0, sizeof kk.B);
-    SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, (const double2*)r0, N, (double2*)n0, pw + PW_T0));
-    SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, (const double2*)r1, N, (double2*)n1, pw + PW_T1));
+    SLAM_TRY(slam_launch(ctx, -1, k_normalize_pair, dim3(2), dim3(1024), 0, (const double2*)r0, (const double2*)r1, N,
+                         (double2*)n0, (double2*)n1, pw + PW_T0, pw + PW_T1));
     SLAM_TRY(ransac_enqueue(ctx, n0, n1, N, nullptr, SLAM_SAMPLER_CPYTHON, SLAM_SEED_BASE, 0, H, SLAM_DEFAULT_THRESHOLD,
                             d_record, nullptr, nullptr, nullptr, nullptr));
     SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1), dim3(64), 0, kk, (const double*)d_record, pw, d_counts4));
     SLAM_TRY(tri4_enqueue(ctx, r0, r1, N, d_counts4));
-    SLAM_TRY(slam_launch(ctx, -1, k_pose_select, dim3(1), dim3(64), 0, (const double*)pw,
-                         (const unsigned long long*)d_counts4, d_pose, d_winner));
     const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)N * 3 + 255) / 256, 4096);
-    SLAM_TRY(slam_launch(ctx, -1, k_emit_points, dim3(blocks), dim3(256), 0, (const double*)ctx->X4.p,
-                         (const int32_t*)d_winner, (int64_t)N, (double*)ctx->X.p, (uint8_t*)ctx->mask.p));
+    SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(blocks), dim3(256), 0, (const double*)pw,
+                         (const unsigned long long*)d_counts4, (const double*)ctx->X4.p, (int64_t)N, d_pose, d_winner,
+                         (double*)ctx->X.p, (uint8_t*)ctx->mask.p));
     if (X) SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (good) SLAM_HIP(ctx, hipMemcpyAsync(good, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-    double* hs = ctx->h_small;
-    SLAM_HIP(ctx, hipMemcpyAsync(hs, pw + PW_E, 18 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));  // E, F
-    SLAM_HIP(ctx, hipMemcpyAsync(hs + 32, d_counts4, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(hs + 40, d_pose, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(hs + 60, d_winner, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(hs + 64, d_record, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double* hs = ctx->h_small;  // mirrors the device block `small` (1024 words)
+    SLAM_HIP(ctx, hipMemcpyAsync(hs, small, 760 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_TRY(check_flags(ctx));
-    if (E) memcpy(E, hs, 9 * sizeof(double));
-    if (F) memcpy(F, hs + 9, 9 * sizeof(double));
-    if (pose) memcpy(pose, hs + 40, 16 * sizeof(double));
-    if (record) memcpy(record, hs + 64, SLAM_REC_LEN * sizeof(double));
-    const int64_t* c = (const int64_t*)(hs + 32);
+    if (E) memcpy(E, hs + PW_E, 9 * sizeof(double));
+    if (F) memcpy(F, hs + PW_F, 9 * sizeof(double));
+    if (pose) memcpy(pose, hs + 710, 16 * sizeof(double));
+    if (record) memcpy(record, hs + 740, SLAM_REC_LEN * sizeof(double));
+    const int64_t* c = (const int64_t*)(hs + 700);
     if (counts4) for (int i = 0; i < 4; ++i) counts4[i] = (int32_t)c[i];
-    if (winner) *winner = *(const int32_t*)(hs + 60);
+    if (winner) *winner = *(const int32_t*)(hs + 730);
     return SLAM_OK;
 }
 
@@ -955,19 +950,18 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
         double* x4 = X4 + 4 * 3 * off;
         ctx->cur = lanes ? ctx->lane_stream[l] : ctx->stream;
         auto go = [&]() -> int {
-            SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, a0, N, (double2*)m0, pw + PW_T0));
-            SLAM_TRY(slam_launch(ctx, -1, k_normalize, dim3(1), dim3(1024), 0, a1, N, (double2*)m1, pw + PW_T1));
+            SLAM_TRY(slam_launch(ctx, -1, k_normalize_pair, dim3(2), dim3(1024), 0, a0, a1, N, (double2*)m0, (double2*)m1,
+                                 pw + PW_T0, pw + PW_T1));
             SLAM_TRY(ransac_enqueue(ctx, m0, m1, N, nullptr, SLAM_SAMPLER_CPYTHON, SLAM_SEED_BASE, 0, H,
                                     SLAM_DEFAULT_THRESHOLD, blk + PB_REC, nullptr, (int32_t*)ctx->lane_counts[l].p,
                                     (double*)ctx->lane_errsums[l].p, (double*)ctx->lane_F[l].p));
             SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1), dim3(64), 0, kk, (const double*)(blk + PB_REC), pw, d_counts4));
             SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
                                  (const double*)pw, a0, a1, (int64_t)N, x4, d_counts4));
-            SLAM_TRY(slam_launch(ctx, -1, k_pose_select, dim3(1), dim3(64), 0, (const double*)pw,
-                                 (const unsigned long long*)d_counts4, blk + PB_POSE, (int32_t*)(blk + PB_WIN)));
             const unsigned eb = (unsigned)std::min<int64_t>(((int64_t)N * 3 + 255) / 256, 4096);
-            SLAM_TRY(slam_launch(ctx, -1, k_emit_points, dim3(eb), dim3(256), 0, (const double*)x4,
-                                 (const int32_t*)(blk + PB_WIN), (int64_t)N, dX + 3 * off, dmask + off));
+            SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(eb), dim3(256), 0, (const double*)pw,
+                                 (const unsigned long long*)d_counts4, (const double*)x4, (int64_t)N, blk + PB_POSE,
+                                 (int32_t*)(blk + PB_WIN), dX + 3 * off, dmask + off));
             return SLAM_OK;
         };
         rc = go();

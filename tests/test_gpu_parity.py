@@ -571,3 +571,20 @@ def test_prepared_job_equals_direct_call(ctx):
     bad = C.c_void_p()
     assert lib.slam_ransac_job_create(ctx.handle, p0.data_ptr(), p1.data_ptr(), 7, None, 0, 0, 0, 10, 0.005, rec_b.data_ptr(),
                                       None, None, None, None, C.byref(bad)) == -1 and not bad.value
+
+
+def test_sampler_against_the_interpreter(ctx):
+    """The GPU draw against CPython's random module itself, on random sizes and on sizes around the branches of
+    random.sample (pool for N <= 85 at k = 8, set otherwise; power-of-two boundaries of getrandbits)."""
+    import random
+    rng = np.random.default_rng(23)
+    sizes = [8, 9, 20, 21, 22, 84, 85, 86, 127, 128, 129, 511, 512, 513, 65535, 65536, 65537] + \
+        [int(x) for x in rng.integers(8, 1 << 21, 60)]
+    for N in sizes:
+        for k in (8, 6):
+            it0 = int(rng.integers(0, 1 << 16))
+            idx = np.empty((16, k), dtype=np.int32)
+            ctx.check(ctx.lib.slam_sample_indices(ctx.handle, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE, it0, 16, N, k, _lib.ptr(idx)))
+            for h in range(16):
+                random.seed(_lib.SEED_BASE + it0 + h)
+                assert idx[h].tolist() == random.sample(range(N), k), (N, k, it0 + h)

@@ -175,3 +175,26 @@ def test_matching_three_nearest():
     for impl in (so.match_knn_brute_force, co.match_knn):
         index, distance = impl(g["k3_des0"], g["k3_des1"], 3)
         assert np.array_equal(index, g["k3_knn_index"]) and np.array_equal(distance, g["k3_knn_distance"])
+
+
+# ---------------------------------------------------------------------------------------------- sampler vs the interpreter
+def test_samplers_replay_the_interpreters_generator():
+    """The restated samplers against CPython's own random module (the generator the reference calls,
+    src/epipolar.py:70-71 and src/triangulation.py:154-155), on sizes around every branch of random.sample."""
+    import random
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(17)
+    sizes = [8, 9, 16, 20, 21, 22, 63, 64, 65, 84, 85, 86, 87, 127, 128, 129, 1023, 1024, 1025] + \
+        [int(x) for x in rng.integers(8, 1 << 21, 40)]
+    for N in sizes:
+        for k in (8, 6):
+            its = [0, 1, 2, 3, 999, int(rng.integers(0, 1 << 20))]
+            want = []
+            for it in its:
+                random.seed(so.SEED_BASE + it)
+                want.append(random.sample(range(N), k))
+            want = np.array(want, dtype=np.int32)
+            got = np.array([so.sample_indices(N, it + 1, k=k)[it] for it in its[:4]], dtype=np.int32)
+            assert np.array_equal(got, want[:4]), (N, k)
+            for j, it in enumerate(its):
+                assert np.array_equal(co.sample(N, 1, k=k, it0=it)[0], want[j]), (N, k, it)

@@ -357,9 +357,9 @@ def main():
     # ---- aux: batched sequence, 100 frame pairs sharded over the ranks, whole initialisation per pair (host buffers)
     if not args.no_aux:
         from slam_amd import pipeline
-        NP_, NB, IB = 100, 2000, 1000
+        NP_, NB, IB = 100, 2048, 1000
         mine = [i for i in range(NP_) if i % world == rank]
-        pdata = [synth.make_pair(NB, 0.3, seed=400 + i) for i in mine]
+        pdata = [synth.make_pair(NB, 0.3, seed=100 + i) for i in mine]
         plist = [(d["pts0"], d["pts1"]) for d in pdata]
         Kb = pdata[0]["K"]
         pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)           # warm-up (buffers, sampler table)

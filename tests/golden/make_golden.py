@@ -354,6 +354,33 @@ def gen_matching():
     np.savez_compressed(os.path.join(HERE, "matching.npz"), **out)
 
 
+def gen_config1():
+    """The reference's own driver sequence (custom_slam.py:56-82 after the ORB calls, then :96-115) on a synthetic
+    stand-in for its bundled image pair: 500 keypoints per image (ORB's default budget) with 256-bit descriptors at
+    the intrinsics the driver hard-codes (custom_slam.py:260-262), 1000 RANSAC iterations (the default)."""
+    d = synth.make_feature_pair(150, n_clutter=350, seed=111, K=synth.REFERENCE_K, size=synth.REFERENCE_SIZE)
+    K = d["K"]
+    bits0, bits1 = np.unpackbits(d["des0"], axis=1), np.unpackbits(d["des1"], axis=1)    # as custom_slam.py:51
+    knn = custom_slam.match_knn_brute_force(bits0, bits1, 2)
+    m0, m1 = [], []
+    for idx, (m, n) in enumerate(knn):                                                  # custom_slam.py:65-70
+        if m["distance"] < 0.5 * n["distance"]:
+            m0.append(d["kp0"][idx])
+            m1.append(d["kp1"][m["index"]])
+    m0, m1 = np.asarray(m0), np.asarray(m1)
+    buf = io.StringIO()
+    logger.set_log_level("DEBUG")
+    with contextlib.redirect_stdout(buf):
+        F = custom_slam.normalize_points_and_find_fundamental_matrix(m0, m1)            # :107
+        E = epipolar.fundamental_to_essential_matrix(F, K)                              # :108
+        pose, X = epipolar.calculate_pose_from_essential_matrix(E, m0, m1, K)           # :109-112
+    logger.set_log_level("WARN")
+    np.savez_compressed(os.path.join(HERE, "config1.npz"), kp0=d["kp0"], des0=d["des0"], kp1=d["kp1"], des1=d["des1"], K=K,
+                        matched0=m0, matched1=m1, F=F, E=E, pose=pose, X=X, good=X[:, 2] > 0, true_R=d["R"], true_t=d["t"],
+                        log=np.array(buf.getvalue()))
+    print("config1: matches", len(m0), buf.getvalue().strip().replace("\n", " | "))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -368,4 +395,5 @@ if __name__ == "__main__":
     gen_pose()
     gen_tracking()
     gen_matching()
+    gen_config1()
     print("python", sys.version.split()[0], "numpy", np.__version__)

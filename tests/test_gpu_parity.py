@@ -588,3 +588,52 @@ def test_sampler_against_the_interpreter(ctx):
             for h in range(16):
                 random.seed(_lib.SEED_BASE + it0 + h)
                 assert idx[h].tolist() == random.sample(range(N), k), (N, k, it0 + h)
+
+
+# ---------------------------------------------------------------------------------------------- configuration 1
+def test_config1_whole_chain_matches_reference(ctx):
+    """The reference driver's sequence on 500 + 500 keypoints at its own intrinsics, against what the reference's
+    functions returned: in one library call, and through the drop-in modules called the way custom_slam.py calls them."""
+    g = load_golden("config1")
+    r = pipeline.frame_pair(g["kp0"], g["des0"], g["kp1"], g["des1"], g["K"], iterations=1000, ctx=ctx)
+    assert np.array_equal(r["matched0"], g["matched0"]) and np.array_equal(r["matched1"], g["matched1"])
+    assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(g["F"])) < F_TOL
+    assert rel_err(fix_sign_scale(r["E"]), fix_sign_scale(g["E"])) < F_TOL
+    assert np.allclose(r["pose"], g["pose"], atol=1e-7)
+    assert point_err(r["X"], g["X"]) < X_TOL
+    assert np.array_equal(r["mask"], g["good"])
+
+
+def test_config1_through_the_drop_in_modules(ctx, capsys):
+    import importlib
+    import sys
+    for name in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[name]
+    src_epipolar = importlib.import_module("src.epipolar")
+    src_logger = importlib.import_module("src.logger")
+    assert "slam_amd" in src_epipolar.calculate_fundamental_matrix_with_ransac.__module__
+    from slam_amd import matching
+    g = load_golden("config1")
+    K = g["K"]
+    # custom_slam.py:60-73, :96-102, :107-115 with the reference's names
+    m0, m1 = matching.matches_between_keypoints(g["kp0"], np.unpackbits(g["des0"], axis=1), g["kp1"],
+                                                np.unpackbits(g["des1"], axis=1), ctx)
+    src_logger.set_log_level("DEBUG")
+    try:
+        n0, T0 = pipeline.normalize_points(m0)
+        n1, T1 = pipeline.normalize_points(m1)
+        F = src_epipolar.calculate_fundamental_matrix_with_ransac(n0, n1)
+        F = T1.T @ F @ T0
+        E = src_epipolar.fundamental_to_essential_matrix(F, K)
+        pose, X = src_epipolar.calculate_pose_from_essential_matrix(E, m0, m1, K)
+    finally:
+        src_logger.set_log_level("WARN")
+    assert rel_err(fix_sign_scale(F), fix_sign_scale(g["F"])) < F_TOL
+    assert np.allclose(pose, g["pose"], atol=1e-7)
+    assert point_err(X, g["X"]) < X_TOL
+    assert np.array_equal(X[:, 2] > 0, g["good"])
+    out = capsys.readouterr().out
+    want = str(g["log"]).splitlines()
+    assert want[0].split("error:")[0] in out          # inlier count line (the error sum is compared numerically below)
+    assert abs(float(out.split("error:")[1].split()[0]) / float(want[0].split("error:")[1]) - 1) < 1e-6
+    assert want[1] in out                             # "essential matrix - winning num points: 85/150"

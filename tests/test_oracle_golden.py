@@ -198,3 +198,19 @@ def test_samplers_replay_the_interpreters_generator():
             assert np.array_equal(got, want[:4]), (N, k)
             for j, it in enumerate(its):
                 assert np.array_equal(co.sample(N, 1, k=k, it0=it)[0], want[j]), (N, k, it)
+
+
+# ---------------------------------------------------------------------------------------------- configuration 1, whole chain
+def test_config1_chain_restatement_matches_reference():
+    """Keypoints + descriptors -> matches -> F -> E -> pose and points at the reference driver's intrinsics: the numpy
+    restatement against what the reference's own functions returned for the same input."""
+    g = load_golden("config1")
+    index, distance = so.match_knn_brute_force(g["des0"], g["des1"], 2)
+    m0, m1, _ = so.select_matches(g["kp0"], g["kp1"], index, distance)
+    assert np.array_equal(m0, g["matched0"]) and np.array_equal(m1, g["matched1"])
+    r = so.initialise_pair(m0, m1, g["K"], iterations=1000)
+    assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(g["F"])) < 1e-9
+    assert rel_err(fix_sign_scale(r["E"]), fix_sign_scale(g["E"])) < 1e-9
+    assert np.allclose(r["pose"], g["pose"], atol=1e-9)
+    assert rel_err(r["X"], g["X"]) < 1e-7
+    assert np.array_equal(r["mask"], g["good"])

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernels_tri.h"  // PairArgs
 #include "linalg.h"
 
 namespace slamk {
@@ -499,10 +500,16 @@ __device__ __forceinline__ void barrier_lds_only() {
 }
 
 template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
-__global__ __launch_bounds__(64 * WAVES, 32 / WAVES) void k_ransac(
+__global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? 48 : 32) / WAVES) void k_ransac(
     const double2* __restrict__ p0, const double2* __restrict__ p1, int N, const int32_t* __restrict__ idx_in,
     uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw, int64_t raw_it0, double rcut,
-    double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags) {
+    double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags,
+    const PairArgs* __restrict__ batch) {
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        p0 = a.n0; p1 = a.n1; N = a.N; H = a.H; Fout = a.F_all; counts = a.counts; errsums = a.errsums;
+        if ((int)blockIdx.x * HB >= H) return;  // the grid is sized for the pair with most hypotheses
+    }
     static_assert(HB == 8 && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves eight hypotheses, eight lanes each");
     __shared__ double s_F[HB][9];
     __shared__ double s_err[HB][WAVES];
@@ -619,7 +626,12 @@ __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ cou
                                                  const int32_t* __restrict__ index_of,  // NULL: entry h is hypothesis h
                                                  const double* __restrict__ Fall, int H, int64_t it0,
                                                  const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
-                                                 double rcut, double* __restrict__ record, uint8_t* __restrict__ mask) {
+                                                 double rcut, double* __restrict__ record, uint8_t* __restrict__ mask,
+                                                 const PairArgs* __restrict__ batch) {
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        counts = a.counts; errsums = a.errsums; Fall = a.F_all; H = a.H; p0 = a.n0; p1 = a.n1; N = a.N; record = a.record;
+    }
     __shared__ Best s_best[16];
     const int tid = threadIdx.x;
     // the winner's mask needs every match: fetch this thread's first matches while the reduction runs

@@ -77,6 +77,25 @@ struct Mat3x2 {  // kernel argument: two 3x3 matrices
     double B[9];
 };
 
+// One pair of a batched call (slam_init_pairs): the arguments the pair pipeline's kernels would get for this pair.
+// A kernel launched with a non-NULL `batch` takes its arguments from batch[blockIdx.y] instead of its parameters.
+struct PairArgs {
+    const double2 *r0, *r1;       // matches in pixel coordinates
+    double2 *n0, *n1;             // their normalised copies
+    int N, H;
+    double* pw;                   // pose work block (PW_*)
+    double* F_all;                // H x 9   }
+    int32_t* counts;              // H       } hypothesis scratch
+    double* errsums;              // H       }
+    double* record;               // SLAM_REC_LEN
+    unsigned long long* counts4;  // 4
+    double* X4;                   // 4 x N x 3
+    double* X;                    // N x 3
+    uint8_t* good;                // N
+    double* pose;                 // 16
+    int32_t* winner;
+};
+
 // K4a: plain triangulation with one camera pair (slam_triangulate)
 __global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* __restrict__ p0,
                                                      const double2* __restrict__ p1, int64_t N,
@@ -97,8 +116,14 @@ __global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* _
 __global__ __launch_bounds__(256) void k_triangulate4(const double* __restrict__ pw, const double2* __restrict__ p0,
                                                       const double2* __restrict__ p1, int64_t N,
                                                       double* __restrict__ X4,
-                                                      unsigned long long* __restrict__ counts4) {
+                                                      unsigned long long* __restrict__ counts4,
+                                                      const PairArgs* __restrict__ batch) {
     __shared__ int s_cnt[4][4];
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        pw = a.pw; p0 = a.r0; p1 = a.r1; N = a.N; X4 = a.X4; counts4 = a.counts4;
+        if ((int64_t)blockIdx.x * 256 >= N) return;  // the grid is sized for the largest pair
+    }
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     const bool live = i < N;
@@ -254,7 +279,12 @@ __global__ __launch_bounds__(64) void k_pose_prepare(Mat3x2 ek, double* __restri
 
 // pair pipeline middle step: denormalise the RANSAC winner (custom_slam.py:101: T1^T F T0), F -> E, candidates
 __global__ __launch_bounds__(64) void k_pair_mid(Mat3x2 kk /* A = K */, const double* __restrict__ record,
-                                                 double* __restrict__ pw, unsigned long long* __restrict__ counts4) {
+                                                 double* __restrict__ pw, unsigned long long* __restrict__ counts4,
+                                                 const PairArgs* __restrict__ batch) {
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        record = a.record; pw = a.pw; counts4 = a.counts4;
+    }
     if (threadIdx.x < 4) counts4[threadIdx.x] = 0ull;
     if (threadIdx.x != 0) return;
     for (int i = 0; i < 9; ++i) pw[PW_K + i] = kk.A[i];
@@ -357,8 +387,13 @@ __global__ __launch_bounds__(1024) void k_normalize(const double2* __restrict__ 
 // both images of a pair in one launch: workgroup 0 normalises pa into outa / Ta, workgroup 1 pb into outb / Tb
 __global__ __launch_bounds__(1024) void k_normalize_pair(const double2* __restrict__ pa, const double2* __restrict__ pb,
                                                          int N, double2* __restrict__ outa, double2* __restrict__ outb,
-                                                         double* __restrict__ Ta, double* __restrict__ Tb) {
+                                                         double* __restrict__ Ta, double* __restrict__ Tb,
+                                                         const PairArgs* __restrict__ batch) {
     __shared__ double s_red[16];
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        pa = a.r0; pb = a.r1; N = a.N; outa = a.n0; outb = a.n1; Ta = a.pw + PW_T0; Tb = a.pw + PW_T1;
+    }
     const bool second = blockIdx.x != 0;
     const double2* __restrict__ p = second ? pb : pa;
     double2* __restrict__ out = second ? outb : outa;
@@ -392,7 +427,11 @@ __global__ __launch_bounds__(256) void k_select_emit(const double* __restrict__ 
                                                      const unsigned long long* __restrict__ counts4,
                                                      const double* __restrict__ X4, int64_t N, double* __restrict__ pose,
                                                      int32_t* __restrict__ winner, double* __restrict__ X,
-                                                     uint8_t* __restrict__ good) {
+                                                     uint8_t* __restrict__ good, const PairArgs* __restrict__ batch) {
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        pw = a.pw; counts4 = a.counts4; X4 = a.X4; N = a.N; pose = a.pose; winner = a.winner; X = a.X; good = a.good;
+    }
     long long best = -1;
     int w = 0;
 #pragma unroll

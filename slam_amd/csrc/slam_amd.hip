@@ -351,7 +351,7 @@ static int launch_fused(slam_ctx* ctx, const double2* p0, const double2* p1, int
     int32_t* flags = (int32_t*)ctx->flags.p;
 #define SLAM_CALL(PPL, WAVES)                                                                                         \
     return slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, p0, p1, N, \
-                       d_idx, seed, it0, H, raw, ctx->raw_it0, thr, F, counts, errsums, flags)
+                       d_idx, seed, it0, H, raw, ctx->raw_it0, thr, F, counts, errsums, flags, (const PairArgs*)nullptr)
     SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
 }
@@ -427,10 +427,10 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     }
     if (ctx->sampson)
         SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<true>, dim3(1), dim3(1024), 0, sel_counts, sel_errsums, sel_index,
-                             (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask));
+                             (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask, (const PairArgs*)nullptr));
     else
         SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1), dim3(1024), 0, sel_counts, sel_errsums, sel_index,
-                             (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask));
+                             (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask, (const PairArgs*)nullptr));
     return SLAM_OK;
 }
 
@@ -607,12 +607,12 @@ extern "C" int slam_ransac_f_adaptive(slam_ctx* ctx, const double* p0, const dou
             SLAM_TRY(slam_launch(ctx, -1, k_select<true>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
                                  (const double*)ctx->errsums.p, (const int32_t*)nullptr, (const double*)dF, 1,
                                  (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
-                                 cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p));
+                                 cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p, (const PairArgs*)nullptr));
         else
             SLAM_TRY(slam_launch(ctx, -1, k_select<false>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
                                  (const double*)ctx->errsums.p, (const int32_t*)nullptr, (const double*)dF, 1,
                                  (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
-                                 cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p));
+                                 cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p, (const PairArgs*)nullptr));
         SLAM_HIP(ctx, hipMemcpyAsync(mask, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
         SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -740,7 +740,7 @@ static int tri4_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, i
     SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
     return slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
                        (const double*)ctx->small.p, (const double2*)d_p0, (const double2*)d_p1, N, (double*)ctx->X4.p,
-                       d_counts4);
+                       d_counts4, (const PairArgs*)nullptr);
 }
 
 extern "C" int slam_pose_candidates_dev(slam_ctx* ctx, const double* E_host, const double* K_host, const double* d_p0,
@@ -843,15 +843,15 @@ static int init_pair_on_device(slam_ctx* ctx, const double* r0, const double* r1
     memcpy(kk.A, K, sizeof kk.A);
     memset(kk.B, 0, sizeof kk.B);
     SLAM_TRY(slam_launch(ctx, -1, k_normalize_pair, dim3(2), dim3(1024), 0, (const double2*)r0, (const double2*)r1, N,
-                         (double2*)n0, (double2*)n1, pw + PW_T0, pw + PW_T1));
+                         (double2*)n0, (double2*)n1, pw + PW_T0, pw + PW_T1, (const PairArgs*)nullptr));
     SLAM_TRY(ransac_enqueue(ctx, n0, n1, N, nullptr, SLAM_SAMPLER_CPYTHON, SLAM_SEED_BASE, 0, H, SLAM_DEFAULT_THRESHOLD,
                             d_record, nullptr, nullptr, nullptr, nullptr));
-    SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1), dim3(64), 0, kk, (const double*)d_record, pw, d_counts4));
+    SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1), dim3(64), 0, kk, (const double*)d_record, pw, d_counts4, (const PairArgs*)nullptr));
     SLAM_TRY(tri4_enqueue(ctx, r0, r1, N, d_counts4));
     const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)N * 3 + 255) / 256, 4096);
     SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(blocks), dim3(256), 0, (const double*)pw,
                          (const unsigned long long*)d_counts4, (const double*)ctx->X4.p, (int64_t)N, d_pose, d_winner,
-                         (double*)ctx->X.p, (uint8_t*)ctx->mask.p));
+                         (double*)ctx->X.p, (uint8_t*)ctx->mask.p, (const PairArgs*)nullptr));
     if (X) SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (good) SLAM_HIP(ctx, hipMemcpyAsync(good, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
     double* hs = ctx->h_small;  // mirrors the device block `small` (1024 words)
@@ -907,74 +907,97 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
     ctx->sampson = false;
     struct Restore { slam_ctx* c; bool v; ~Restore() { c->sampson = v; } } restore_scoring{ctx, scoring_was};
     const int64_t total = offsets[P];
-    const bool lanes = ctx->stream == ctx->own_stream;  // a caller-supplied stream keeps everything in order on it
-    const int L = lanes ? SLAM_LANES : 1;
+    int maxN = 0;
+    for (int p = 0; p < P; ++p) maxN = std::max(maxN, (int)(offsets[p + 1] - offsets[p]));
     // every allocation first: growing a buffer synchronises the context
     const size_t b_pts = align256((size_t)total * 16), b_x = align256((size_t)total * 24), b_m = align256((size_t)total);
-    const size_t b_blk = (size_t)P * PB_LEN * sizeof(double);
-    SLAM_TRY(slam_reserve(ctx, ctx->batch, 4 * b_pts + 5 * b_x + b_m + b_blk));
-    for (int l = 0; l < L; ++l) {
-        SLAM_TRY(slam_reserve(ctx, ctx->lane_F[l], (size_t)maxH * 9 * sizeof(double)));
-        SLAM_TRY(slam_reserve(ctx, ctx->lane_counts[l], (size_t)maxH * sizeof(int32_t)));
-        SLAM_TRY(slam_reserve(ctx, ctx->lane_errsums[l], (size_t)maxH * sizeof(double)));
-    }
+    const size_t b_blk = align256((size_t)P * PB_LEN * sizeof(double));
+    const size_t b_F = align256((size_t)P * maxH * 9 * sizeof(double)), b_c = align256((size_t)P * maxH * sizeof(int32_t));
+    const size_t b_e = align256((size_t)P * maxH * sizeof(double)), b_args = align256((size_t)P * sizeof(PairArgs));
+    SLAM_TRY(slam_reserve(ctx, ctx->batch, 4 * b_pts + 5 * b_x + b_m + b_blk + b_F + b_c + b_e + 3 * b_args));
     SLAM_TRY(slam_fill_raw_table(ctx, SLAM_SEED_BASE, 0, maxH));
-    for (int l = 0; l <= SLAM_LANES; ++l)
-        if (!ctx->lane_event[l]) SLAM_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_event[l], hipEventDisableTiming));
-    char* base = (char*)ctx->batch.p;
-    double *r0 = (double*)base, *r1 = (double*)(base + b_pts), *n0 = (double*)(base + 2 * b_pts), *n1 = (double*)(base + 3 * b_pts);
-    double* X4 = (double*)(base + 4 * b_pts);
-    double* dX = (double*)(base + 4 * b_pts + 4 * b_x);
-    uint8_t* dmask = (uint8_t*)(base + 4 * b_pts + 5 * b_x);
-    double* blocks = (double*)(base + 4 * b_pts + 5 * b_x + b_m);
+    char* at = (char*)ctx->batch.p;
+    auto take = [&](size_t bytes) { char* q = at; at += bytes; return q; };
+    double *r0 = (double*)take(b_pts), *r1 = (double*)take(b_pts), *n0 = (double*)take(b_pts), *n1 = (double*)take(b_pts);
+    double* X4 = (double*)take(4 * b_x);
+    double* dX = (double*)take(b_x);
+    uint8_t* dmask = (uint8_t*)take(b_m);
+    double* blocks = (double*)take(b_blk);
+    double* dF = (double*)take(b_F);
+    int32_t* dC = (int32_t*)take(b_c);
+    double* dE = (double*)take(b_e);
+    PairArgs* d_args = (PairArgs*)take(3 * b_args);  // all pairs, then the same pairs grouped by scoring shape
+    // One launch per stage for the whole batch: blockIdx.y selects the pair, the grid is sized for the largest one.
+    // The scoring kernel's shape (matches per lane) depends on N, so pairs are grouped by shape: at most three launches.
+    std::vector<PairArgs> args((size_t)P), grouped;
+    grouped.reserve((size_t)P);
+    for (int p = 0; p < P; ++p) {
+        const int64_t off = offsets[p];
+        PairArgs& a = args[(size_t)p];
+        double* blk = blocks + (size_t)p * PB_LEN;
+        a.r0 = (const double2*)(r0 + 2 * off); a.r1 = (const double2*)(r1 + 2 * off);
+        a.n0 = (double2*)(n0 + 2 * off); a.n1 = (double2*)(n1 + 2 * off);
+        a.N = (int)(offsets[p + 1] - off);
+        a.H = (int)slam_num_hypotheses(a.N, iterations);
+        a.pw = blk + PB_PW;
+        a.F_all = dF + (size_t)p * maxH * 9; a.counts = dC + (size_t)p * maxH; a.errsums = dE + (size_t)p * maxH;
+        a.record = blk + PB_REC;
+        a.counts4 = (unsigned long long*)(blk + PB_COUNTS);
+        a.X4 = X4 + 4 * 3 * off; a.X = dX + 3 * off; a.good = dmask + off;
+        a.pose = blk + PB_POSE; a.winner = (int32_t*)(blk + PB_WIN);
+    }
+    int class_begin[4] = {0, 0, 0, 0};
+    for (int cls = 0; cls < 3; ++cls) {
+        for (int p = 0; p < P; ++p) {
+            const int N = args[(size_t)p].N;
+            const int c = N <= 512 ? 0 : (N <= 2048 ? 1 : 2);  // the same limits as SLAM_DISPATCH_SHAPE
+            if (c == cls) grouped.push_back(args[(size_t)p]);
+        }
+        class_begin[cls + 1] = (int)grouped.size();
+    }
     SLAM_HIP(ctx, hipMemcpyAsync(r0, pts0, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(r1, pts1, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
-    if (L > 1) {
-        SLAM_HIP(ctx, hipEventRecord(ctx->lane_event[SLAM_LANES], ctx->stream));
-        for (int l = 1; l < L; ++l) SLAM_HIP(ctx, hipStreamWaitEvent(ctx->lane_stream[l], ctx->lane_event[SLAM_LANES], 0));
-    }
+    SLAM_HIP(ctx, hipMemcpyAsync(d_args, args.data(), (size_t)P * sizeof(PairArgs), hipMemcpyHostToDevice, ctx->stream));
+    PairArgs* d_grouped = (PairArgs*)((char*)d_args + b_args);
+    SLAM_HIP(ctx, hipMemcpyAsync(d_grouped, grouped.data(), (size_t)P * sizeof(PairArgs), hipMemcpyHostToDevice, ctx->stream));
     Mat3x2 kk;
     memcpy(kk.A, K, sizeof kk.A);
     memset(kk.B, 0, sizeof kk.B);
-    int rc = SLAM_OK;
-    for (int p = 0; p < P && rc == SLAM_OK; ++p) {
-        const int l = p % L;
-        const int64_t off = offsets[p];
-        const int N = (int)(offsets[p + 1] - off);
-        const int H = (int)slam_num_hypotheses(N, iterations);
-        double* blk = blocks + (size_t)p * PB_LEN;
-        double* pw = blk + PB_PW;
-        unsigned long long* d_counts4 = (unsigned long long*)(blk + PB_COUNTS);
-        const double2 *a0 = (const double2*)(r0 + 2 * off), *a1 = (const double2*)(r1 + 2 * off);
-        double *m0 = n0 + 2 * off, *m1 = n1 + 2 * off;
-        double* x4 = X4 + 4 * 3 * off;
-        ctx->cur = lanes ? ctx->lane_stream[l] : ctx->stream;
-        auto go = [&]() -> int {
-            SLAM_TRY(slam_launch(ctx, -1, k_normalize_pair, dim3(2), dim3(1024), 0, a0, a1, N, (double2*)m0, (double2*)m1,
-                                 pw + PW_T0, pw + PW_T1));
-            SLAM_TRY(ransac_enqueue(ctx, m0, m1, N, nullptr, SLAM_SAMPLER_CPYTHON, SLAM_SEED_BASE, 0, H,
-                                    SLAM_DEFAULT_THRESHOLD, blk + PB_REC, nullptr, (int32_t*)ctx->lane_counts[l].p,
-                                    (double*)ctx->lane_errsums[l].p, (double*)ctx->lane_F[l].p));
-            SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1), dim3(64), 0, kk, (const double*)(blk + PB_REC), pw, d_counts4));
-            SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
-                                 (const double*)pw, a0, a1, (int64_t)N, x4, d_counts4));
-            const unsigned eb = (unsigned)std::min<int64_t>(((int64_t)N * 3 + 255) / 256, 4096);
-            SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(eb), dim3(256), 0, (const double*)pw,
-                                 (const unsigned long long*)d_counts4, (const double*)x4, (int64_t)N, blk + PB_POSE,
-                                 (int32_t*)(blk + PB_WIN), dX + 3 * off, dmask + off));
-            return SLAM_OK;
-        };
-        rc = go();
+    const double rcut = square_cutoff(SLAM_DEFAULT_THRESHOLD);
+    const PairArgs* all = d_args;
+    SLAM_TRY(slam_launch(ctx, -1, k_normalize_pair, dim3(2, P), dim3(1024), 0, (const double2*)nullptr, (const double2*)nullptr, 0,
+                         (double2*)nullptr, (double2*)nullptr, (double*)nullptr, (double*)nullptr, all));
+    for (int cls = 0; cls < 3; ++cls) {
+        const int n_cls = class_begin[cls + 1] - class_begin[cls];
+        if (n_cls == 0) continue;
+        int clsH = 0;
+        for (int q = class_begin[cls]; q < class_begin[cls + 1]; ++q) clsH = std::max(clsH, grouped[(size_t)q].H);
+        const PairArgs* part = d_grouped + class_begin[cls];
+        const dim3 grid((clsH + SLAM_HB - 1) / SLAM_HB, n_cls);
+#define SLAM_BATCH_RANSAC(PPL)                                                                                            \
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, 8, SLAM_SAMPLER_CPYTHON, false>, grid, dim3(512), 0,     \
+                         (const double2*)nullptr, (const double2*)nullptr, 0, (const int32_t*)nullptr,                    \
+                         (uint64_t)SLAM_SEED_BASE, (int64_t)0, 0, (const uint32_t*)ctx->raw.p, ctx->raw_it0, rcut,        \
+                         (double*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)ctx->flags.p, part))
+        if (cls == 0) SLAM_BATCH_RANSAC(1);
+        else if (cls == 1) SLAM_BATCH_RANSAC(4);
+        else SLAM_BATCH_RANSAC(8);
+#undef SLAM_BATCH_RANSAC
     }
-    ctx->cur = ctx->stream;
-    SLAM_TRY(rc);
-    if (L > 1)
-        for (int l = 1; l < L; ++l) {
-            SLAM_HIP(ctx, hipEventRecord(ctx->lane_event[l], ctx->lane_stream[l]));
-            SLAM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_event[l], 0));
-        }
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1, P), dim3(1024), 0, (const int32_t*)nullptr,
+                         (const double*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, 0, (int64_t)0,
+                         (const double2*)nullptr, (const double2*)nullptr, 0, rcut, (double*)nullptr, (uint8_t*)nullptr, all));
+    SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1, P), dim3(64), 0, kk, (const double*)nullptr, (double*)nullptr,
+                         (unsigned long long*)nullptr, all));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((maxN + 255) / 256), P), dim3(256), 0,
+                         (const double*)nullptr, (const double2*)nullptr, (const double2*)nullptr, (int64_t)0,
+                         (double*)nullptr, (unsigned long long*)nullptr, all));
+    const unsigned eb = (unsigned)std::min<int64_t>(((int64_t)maxN * 3 + 255) / 256, 64);
+    SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(eb, P), dim3(256), 0, (const double*)nullptr,
+                         (const unsigned long long*)nullptr, (const double*)nullptr, (int64_t)0, (double*)nullptr,
+                         (int32_t*)nullptr, (double*)nullptr, (uint8_t*)nullptr, all));
     std::vector<double> hb((size_t)P * PB_LEN);
-    SLAM_HIP(ctx, hipMemcpyAsync(hb.data(), blocks, b_blk, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(hb.data(), blocks, hb.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (X) SLAM_HIP(ctx, hipMemcpyAsync(X, dX, (size_t)total * 24, hipMemcpyDeviceToHost, ctx->stream));
     if (good) SLAM_HIP(ctx, hipMemcpyAsync(good, dmask, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
     SLAM_TRY(check_flags(ctx));

@@ -91,3 +91,34 @@ def test_shape_preconditions_raise_like_the_reference():
         epipolar.calculate_fundamental_matrix(np.zeros((7, 2)), np.zeros((7, 2)))
     with pytest.raises(AssertionError):
         epipolar.calculate_fundamental_matrix_with_ransac(np.zeros((9, 2)), np.zeros((8, 2)))
+
+
+def test_hypothesis_counts_follow_the_reference_formulas():
+    """min(iterations, C(n, 8)) for the fundamental-matrix loop (src/epipolar.py:69) and min(iterations, C(m, 6)) for
+    the tracking loop (src/triangulation.py:145-146); both entry points are host-only."""
+    import math
+    lib = _lib.load()
+    for n in (7, 8, 9, 10, 12, 20, 100, 4096, 1 << 20):
+        for it in (1, 44, 45, 1000, 10 ** 9):
+            want = 0 if n < 8 else min(it, math.comb(n, 8))
+            assert lib.slam_num_hypotheses(n, it) == want, (n, it)
+    for m in (5, 6, 7, 8, 9, 12, 300):
+        for it in (1, 7, 28, 100, 10 ** 9):
+            want = 0 if m < 6 else min(it, math.comb(m, 6))
+            assert lib.slam_num_tracking_hypotheses(m, it) == want, (m, it)
+
+
+def test_synthetic_tracking_and_feature_scenes_are_consistent():
+    t = synth.make_track(50, 120, 0.2, seed=3)
+    K = t["K"]
+    # the known points project onto the next-image points of the true matches with the true next pose
+    Xh = np.hstack([t["X_known"], np.ones((50, 1))])
+    proj = (K @ t["next_pose"][:3] @ Xh.T).T
+    uv = proj[:, :2] / proj[:, 2:3]
+    err = np.linalg.norm(uv - t["next_known"], axis=1)
+    assert np.median(err[t["inlier"]]) < 5.0 and err[~t["inlier"]].min() > 5.0
+    f = synth.make_feature_pair(40, n_clutter=30, seed=4)
+    has = f["truth"] >= 0
+    assert has.sum() == 40
+    d = np.unpackbits(f["des0"][has] ^ f["des1"][f["truth"][has]], axis=1).sum(axis=1)
+    assert np.all(d == 20)                        # partners differ in exactly the flipped bits

@@ -6,6 +6,12 @@
 #include <type_traits>
 
 namespace slamk {
+#ifdef SLAM_STAMPS
+__device__ unsigned long long g_dbg[8];
+#define SLAM_DBG_ADD(slot, v) atomicAdd(&g_dbg[slot], (unsigned long long)(v))
+#else
+#define SLAM_DBG_ADD(slot, v) do { } while (0)
+#endif
 
 // Plane rotation that orthogonalises two columns with squared norms a, b and inner product c.
 // Small-angle branch (|theta| <= pi/4):  cos 2t = |b-a|/h, sin 2t = sign(b-a) 2c/h, h = hypot(b-a, 2c).
@@ -92,6 +98,7 @@ __device__ __forceinline__ void jacobi_sweeps(double (&A)[M][N], double (&V)[N][
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (M == 3 && LAST_ONLY) SLAM_DBG_ADD(4, 1);
         bool rotated = false;
         if constexpr (LAST_ONLY) {
             // pairs with the last column first; the rest only for lanes that are not done
@@ -104,7 +111,7 @@ __device__ __forceinline__ void jacobi_sweeps(double (&A)[M][N], double (&V)[N][
                 rotated |= rotate_pair(I2{}, I3{}, true);
             }
             const bool more = rotated || full;
-            if (!__any(more)) break;
+            if (!__any(more)) { if (M == 3) SLAM_DBG_ADD(5 + (sweep > 2 ? 2 : sweep), 1); break; }
             bool others = rotate_pair(I0{}, I1{}, more);
             if constexpr (N == 4) {
                 others |= rotate_pair(I0{}, I2{}, more);
@@ -122,7 +129,7 @@ __device__ __forceinline__ void jacobi_sweeps(double (&A)[M][N], double (&V)[N][
             }
         }
         // leave when no lane of the wave still rotates (keeps the wave converged together)
-        if (!__any(rotated)) break;
+        if (!__any(rotated)) { if (M == 3 && LAST_ONLY) SLAM_DBG_ADD(5 + (sweep > 2 ? 2 : sweep), 1); break; }
     }
 }
 
@@ -332,13 +339,17 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
         for (int c = 0; c < 3; ++c) B[r][c] = f[r][0] * V[0][c] + f[r][1] * V[1][c] + f[r][2] * V[2][c];
     // only v3 enters the projection f (I - v3 v3^T): the third column alone has to converge (lanes without a usable
     // estimate converge every pair and pick the smallest column below)
+    SLAM_DBG_ADD(0, 1);
+    if (!usable) SLAM_DBG_ADD(1, 1);
     jacobi_sweeps<3, 3, true>(B, V, 30, 1e-15, !usable);
     double n2[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];
     // ||f v|| >= sigma_3 for every unit v, so a converged third column can never be longer than another column;
     // if it is, the start was poor and the third column settled on the wrong singular vector: converge every pair
+    if (n2[2] > n2[0] || n2[2] > n2[1]) SLAM_DBG_ADD(2, 1);
     if (__any(n2[2] > n2[0] || n2[2] > n2[1])) {
+        SLAM_DBG_ADD(3, 1);
         jacobi_sweeps<3, 3, false>(B, V, 30, 1e-15);
 #pragma unroll
         for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];

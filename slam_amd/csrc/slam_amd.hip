@@ -1322,6 +1322,9 @@ extern "C" int slam_frame_pair(slam_ctx* ctx, const uint8_t* des0, const double*
 extern "C" int slam_debug_stamps(slam_ctx* ctx, long long* out, int n) {
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SLAM_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(slamk::g_stamps), sizeof(long long) * (size_t)n));
+    unsigned long long dbg[8];
+    SLAM_HIP(ctx, hipMemcpyFromSymbol(dbg, HIP_SYMBOL(slamk::g_dbg), sizeof dbg));
+    fprintf(stderr, "dbg: calls %llu unusable %llu wrong-column lanes %llu safety-net lanes %llu last-only sweeps (lane-sweeps) %llu; exits after 1/2/3+ sweeps %llu %llu %llu\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
     return SLAM_OK;
 }
 #endif

@@ -37,5 +37,7 @@ names = ["sample", "solve", "barrier", "score", "reduce"]
 d = np.diff(st, axis=1)
 print(f"N={N} H={H} blocks={nb}; cycles (shader clock) median over workgroups")
 for i, nme in enumerate(names):
-    print(f"  {nme:8s} median {np.median(d[:, i]):9.0f}  max {d[:, i].max():9.0f}")
-print(f"  start spread {np.ptp(st[:, 0]):.0f}  end-to-end {st[:, 5].max() - t0:.0f} cycles")
+    q = np.quantile(d[:, i], [0.5, 0.9, 0.99])
+    print(f"  {nme:8s} median {q[0]:9.0f}  90% {q[1]:9.0f}  99% {q[2]:9.0f}  max {d[:, i].max():9.0f}")
+tot = st[:, 5] - st[:, 0]
+print(f"  workgroup total median {np.median(tot):.0f}  max {tot.max():.0f}; first start to last end {st[:, 5].max() - t0:.0f} cycles")

@@ -367,8 +367,10 @@ struct MatchChunk {  // PPL matches per lane of a chunk of 64*WAVES*PPL, plus wh
             const int i = base + k * 64 * WAVES + (int)threadIdx.x;
             live[k] = i < N;
             livemask[k] = __ballot(live[k]);
-            const int ii = live[k] ? i : N - 1;
-            const double2 a = p0[ii], b = p1[ii];
+            // one 32-bit byte offset serves both arrays (scalar base + vector offset addressing; the callers keep
+            // N below 2^27 matches)
+            const uint32_t off = (uint32_t)(live[k] ? i : N - 1) * (uint32_t)sizeof(double2);
+            const double2 a = *(const double2*)((const char*)p0 + off), b = *(const double2*)((const char*)p1 + off);
             a0[k] = a.x; a1[k] = a.y; b0[k] = b.x; b1[k] = b.y;
         }
     }
@@ -427,20 +429,19 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
                     continue;
                 }
                 // fl(r*r) < thr  <=>  |r| < rcut (rcut: the smallest double whose rounded square reaches thr).
-                // The compare writes the execution mask itself, so the inlier lanes alone accumulate r*r and the
-                // mask's population count is the inlier count: no select instructions.
-                int n_in;
+                // The compare runs on the real matches only and writes the execution mask itself (and the same bits
+                // to a scalar pair), so the inlier lanes alone accumulate r*r: no select instructions, and no scalar
+                // instruction between the compare and the accumulation.  The population count of the scalar copy is
+                // the inlier count; it is ordinary code that the compiler schedules wherever a slot is free.
                 unsigned long long lt_mask;
                 asm volatile(
+                    "s_mov_b64 exec, %[live]\n\t"
                     "v_cmpx_lt_f64_e64 %[lt], |%[r]|, %[rc]\n\t"
-                    "s_and_b64 exec, exec, %[live]\n\t"
-                    "s_bcnt1_i32_b64 %[n], exec\n\t"
                     "v_fma_f64 %[es], %[r], %[r], %[es]\n\t"
                     "s_mov_b64 exec, %[full]"
-                    : [es] "+v"(es[j]), [n] "=&s"(n_in), [lt] "=&s"(lt_mask)  // written before the inputs are all read
-                    : [r] "v"(r[k]), [rc] "s"(rcut), [live] "s"(m.livemask[k]), [full] "s"(full_exec)
-                    : "scc");
-                cnt[j] += n_in;
+                    : [es] "+v"(es[j]), [lt] "=&s"(lt_mask)  // written before the inputs are all read
+                    : [r] "v"(r[k]), [rc] "s"(rcut), [live] "s"(m.livemask[k]), [full] "s"(full_exec));
+                cnt[j] += __popcll(lt_mask);
             }
         }
     }
@@ -455,6 +456,7 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
             for (int j = 0; j < HB; ++j) s_cnt[j][wave] = cnt[j];
         }
     }
+    SLAM_STAMP(6);
     __syncthreads();
     SLAM_STAMP(5);
     if (tid < HB && h0 + tid < H) {
@@ -544,6 +546,7 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? 48 : 32) / WAVES) void k_ra
         double col[9] = {b.x * a.x, b.x * a.y, b.x, b.y * a.x, b.y * a.y, b.y, a.x, a.y, 1.0};
         double f[9], F[9];
         null_vector_9x8_by_eight_lanes(col, c, f);
+        SLAM_STAMP(7);
         rank2_project(f, F);
         if (c == 0) {
 #pragma unroll

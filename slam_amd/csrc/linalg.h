@@ -5,10 +5,15 @@
 
 #include <type_traits>
 
+#ifndef SLAM_RANK2_TOL
+#define SLAM_RANK2_TOL 1e-15
+#endif
 namespace slamk {
 #ifdef SLAM_STAMPS
-__device__ unsigned long long g_dbg[8];
-#define SLAM_DBG_ADD(slot, v) atomicAdd(&g_dbg[slot], (unsigned long long)(v))
+__device__ unsigned long long g_dbg[8];  // sweep statistics of the rank-2 projection; counted only with SLAM_COUNT_SWEEPS
+#endif
+#if defined(SLAM_STAMPS) && defined(SLAM_COUNT_SWEEPS)
+#define SLAM_DBG_ADD(slot, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dbg[slot], (unsigned long long)(v)); } while (0)  // per wave
 #else
 #define SLAM_DBG_ADD(slot, v) do { } while (0)
 #endif
@@ -97,39 +102,63 @@ __device__ __forceinline__ void jacobi_sweeps(double (&A)[M][N], double (&V)[N][
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
-    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-        if (M == 3 && LAST_ONLY) SLAM_DBG_ADD(4, 1);
-        bool rotated = false;
-        if constexpr (LAST_ONLY) {
-            // pairs with the last column first; the rest only for lanes that are not done
-            if constexpr (N == 3) {
-                rotated |= rotate_pair(I0{}, I2{}, true);
-                rotated |= rotate_pair(I1{}, I2{}, true);
-            } else {
+    // does a pair still need a rotation?  (the three inner products and the tests of rotate_pair, nothing else)
+    auto needs_pair = [&](auto P, auto Q) -> bool {
+        constexpr int p = decltype(P)::value, q = decltype(Q)::value;
+        double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            a = fma(A[i][p], A[i][p], a);
+            b = fma(A[i][q], A[i][q], b);
+            c = fma(A[i][p], A[i][q], c);
+        }
+        return (a > floor2) && (b > floor2) && (c * c > 1e-30 * (a * b)) && (fabs(c) > angle_tol * fabs(a - b));
+    };
+
+    if constexpr (LAST_ONLY && N == 3) {
+        // A sweep starts by looking at the two pairs with the last column; when neither needs a rotation the lane is
+        // done.  Otherwise the other pair goes FIRST: with columns 0 and 1 orthogonal, rotating each against the last
+        // column is a proper cyclic sweep whose errors square; with them oblique, the second rotation re-opens the
+        // first pair's angle to first order and costs another rotating sweep.
+        bool full_active = full;
+        for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+            if (M == 3) SLAM_DBG_ADD(4, 1);
+            const bool need0 = needs_pair(I0{}, I2{});
+            const bool need1 = needs_pair(I1{}, I2{});
+            const bool more = need0 || need1 || full_active;
+            if (!__any(more)) { if (M == 3) SLAM_DBG_ADD(5 + (sweep > 2 ? 2 : sweep), 1); break; }
+            const bool r01 = rotate_pair(I0{}, I1{}, more);
+            const bool r02 = rotate_pair(I0{}, I2{}, true);
+            const bool r12 = rotate_pair(I1{}, I2{}, true);
+            full_active = full && (r01 || r02 || r12);
+        }
+    } else {
+        for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+            bool rotated = false;
+            if constexpr (LAST_ONLY) {  // N == 4
+                // pairs with the last column first; the rest only for lanes that are not done
                 rotated |= rotate_pair(I0{}, I3{}, true);
                 rotated |= rotate_pair(I1{}, I3{}, true);
                 rotated |= rotate_pair(I2{}, I3{}, true);
-            }
-            const bool more = rotated || full;
-            if (!__any(more)) { if (M == 3) SLAM_DBG_ADD(5 + (sweep > 2 ? 2 : sweep), 1); break; }
-            bool others = rotate_pair(I0{}, I1{}, more);
-            if constexpr (N == 4) {
+                const bool more = rotated || full;
+                if (!__any(more)) break;
+                bool others = rotate_pair(I0{}, I1{}, more);
                 others |= rotate_pair(I0{}, I2{}, more);
                 others |= rotate_pair(I1{}, I2{}, more);
+                rotated |= full && others;
+            } else {
+                rotated |= rotate_pair(I0{}, I1{}, true);
+                rotated |= rotate_pair(I0{}, I2{}, true);
+                if constexpr (N == 4) rotated |= rotate_pair(I0{}, I3{}, true);
+                rotated |= rotate_pair(I1{}, I2{}, true);
+                if constexpr (N == 4) {
+                    rotated |= rotate_pair(I1{}, I3{}, true);
+                    rotated |= rotate_pair(I2{}, I3{}, true);
+                }
             }
-            rotated |= full && others;
-        } else {
-            rotated |= rotate_pair(I0{}, I1{}, true);
-            rotated |= rotate_pair(I0{}, I2{}, true);
-            if constexpr (N == 4) rotated |= rotate_pair(I0{}, I3{}, true);
-            rotated |= rotate_pair(I1{}, I2{}, true);
-            if constexpr (N == 4) {
-                rotated |= rotate_pair(I1{}, I3{}, true);
-                rotated |= rotate_pair(I2{}, I3{}, true);
-            }
+            // leave when no lane of the wave still rotates (keeps the wave converged together)
+            if (!__any(rotated)) break;
         }
-        // leave when no lane of the wave still rotates (keeps the wave converged together)
-        if (!__any(rotated)) { if (M == 3 && LAST_ONLY) SLAM_DBG_ADD(5 + (sweep > 2 ? 2 : sweep), 1); break; }
     }
 }
 
@@ -341,7 +370,7 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
     // estimate converge every pair and pick the smallest column below)
     SLAM_DBG_ADD(0, 1);
     if (!usable) SLAM_DBG_ADD(1, 1);
-    jacobi_sweeps<3, 3, true>(B, V, 30, 1e-15, !usable);
+    jacobi_sweeps<3, 3, true>(B, V, 30, SLAM_RANK2_TOL, !usable);
     double n2[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];

@@ -383,11 +383,14 @@ static int launch_ransac(slam_ctx* ctx, const double2* p0, const double2* p1, in
                  : launch_split<SAMPLER, false>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
 }
 
+static constexpr int SLAM_MAX_MATCHES = 1 << 27;
+
 static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                           int sampler, uint64_t seed, int64_t it0, int H, double thr, double* d_record,
                           uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all) {
     SLAM_REQUIRE(ctx, d_p0 && d_p1 && d_record, "points or record pointer is NULL");
     SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");          // reference: src/epipolar.py:60
+    SLAM_REQUIRE(ctx, N <= SLAM_MAX_MATCHES, "more than 2^27 matches");  // the kernels address matches by 32-bit byte offsets
     SLAM_REQUIRE(ctx, H >= 1 && it0 >= 0, "H < 1 or it0 < 0");
     SLAM_REQUIRE(ctx, d_idx || sampler == SLAM_SAMPLER_CPYTHON || sampler == SLAM_SAMPLER_COUNTER, "unknown sampler");
     SLAM_REQUIRE(ctx, !d_idx || ((uintptr_t)d_idx & 15) == 0, "idx must be 16-byte aligned");
@@ -899,7 +902,7 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
     int maxH = 0;
     for (int p = 0; p < P; ++p) {
         const int64_t n = offsets[p + 1] - offsets[p];
-        SLAM_REQUIRE(ctx, n >= 8 && n <= INT32_MAX, "a pair has fewer than 8 matches (or too many)");
+        SLAM_REQUIRE(ctx, n >= 8 && n <= SLAM_MAX_MATCHES, "a pair has fewer than 8 matches (or more than 2^27)");
         maxH = std::max(maxH, (int)slam_num_hypotheses(n, iterations));
     }
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
@@ -1324,7 +1327,7 @@ extern "C" int slam_debug_stamps(slam_ctx* ctx, long long* out, int n) {
     SLAM_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(slamk::g_stamps), sizeof(long long) * (size_t)n));
     unsigned long long dbg[8];
     SLAM_HIP(ctx, hipMemcpyFromSymbol(dbg, HIP_SYMBOL(slamk::g_dbg), sizeof dbg));
-    fprintf(stderr, "dbg: calls %llu unusable %llu wrong-column lanes %llu safety-net lanes %llu last-only sweeps (lane-sweeps) %llu; exits after 1/2/3+ sweeps %llu %llu %llu\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+    fprintf(stderr, "dbg (per wave): projections %llu unusable starts %llu wrong column %llu safety net %llu sweeps %llu; left after 1/2/3+ sweeps %llu %llu %llu\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
     return SLAM_OK;
 }
 #endif

@@ -1,0 +1,59 @@
+// Issue rate and dependent latency of v_fma_f64 on one CU: CHAINS independent chains per lane, W waves per workgroup.
+// Prints shader-clock cycles per FMA instruction per SIMD and the shader-clock frequency seen by clock64().
+// build: hipcc --offload-arch=gfx950 -O3 -o /tmp/fp64_issue tools/fp64_issue.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+template <int CHAINS>
+__global__ void k(double a, double b, int iters, long long* cycles, double* sink) {
+    double x[CHAINS];
+#pragma unroll
+    for (int i = 0; i < CHAINS; ++i) x[i] = threadIdx.x * 1e-3 + i;
+    __syncthreads();
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < CHAINS; ++i) x[i] = fma(x[i], a, b);
+    }
+    const long long t1 = clock64();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < CHAINS; ++i) s += x[i];
+    if (s == 12345.678) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int CHAINS>
+void run(int waves, long long* d_cycles, double* d_sink) {
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<CHAINS>, dim3(1), dim3(64 * waves), 0, 0, 0.999, 1e-3, iters, d_cycles, d_sink);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<CHAINS>, dim3(1), dim3(64 * waves), 0, 0, 0.999, 1e-3, iters, d_cycles, d_sink);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(16);
+    hipMemcpy(h.data(), d_cycles, 16 * sizeof(long long), hipMemcpyDeviceToHost);
+    long long mx = 0;
+    for (int w = 0; w < waves; ++w) mx = h[w] > mx ? h[w] : mx;
+    const double instr_per_simd = (double)iters * 8 * CHAINS * ((waves + 3) / 4);
+    printf("chains %d waves %2d: %8lld cycles, %.2f cycles per FMA per SIMD, clock %.0f MHz\n", CHAINS, waves, mx,
+           mx / instr_per_simd, mx / (ms * 1e3));
+}
+
+int main() {
+    long long* d_cycles; double* d_sink;
+    hipMalloc(&d_cycles, 16 * 16 * sizeof(long long)); hipMalloc(&d_sink, 8);
+    for (int waves : {1, 4, 8, 16}) {
+        run<1>(waves, d_cycles, d_sink);
+        run<2>(waves, d_cycles, d_sink);
+        run<4>(waves, d_cycles, d_sink);
+        run<8>(waves, d_cycles, d_sink);
+    }
+    return 0;
+}

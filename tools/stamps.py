@@ -31,13 +31,17 @@ nb = min(4096, (H + 7) // 8)
 out = np.zeros(nb * 8, dtype=np.int64)
 lib.slam_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 ctx.check(lib.slam_debug_stamps(ctx.handle, out.ctypes.data, nb * 8))
-st = out.reshape(nb, 8)[:, :6].astype(np.float64)
+raw = out.reshape(nb, 8).astype(np.float64)
+# slots in program order: 0 start, 1 drawn, 7 null vector found, 2 solved, 3 past the barrier, 4 scored,
+# 6 wave totals written, 5 past the last barrier
+order = [0, 1, 7, 2, 3, 4, 6, 5]
+st = raw[:, order]
 t0 = st[:, 0].min()
-names = ["sample", "solve", "barrier", "score", "reduce"]
+names = ["sample", "null vec", "rank-2", "barrier", "score", "wave sum", "barrier"]
 d = np.diff(st, axis=1)
 print(f"N={N} H={H} blocks={nb}; cycles (shader clock) median over workgroups")
 for i, nme in enumerate(names):
     q = np.quantile(d[:, i], [0.5, 0.9, 0.99])
     print(f"  {nme:8s} median {q[0]:9.0f}  90% {q[1]:9.0f}  99% {q[2]:9.0f}  max {d[:, i].max():9.0f}")
-tot = st[:, 5] - st[:, 0]
-print(f"  workgroup total median {np.median(tot):.0f}  max {tot.max():.0f}; first start to last end {st[:, 5].max() - t0:.0f} cycles")
+tot = st[:, -1] - st[:, 0]
+print(f"  workgroup total median {np.median(tot):.0f}  max {tot.max():.0f}; first start to last end {st[:, -1].max() - t0:.0f} cycles")

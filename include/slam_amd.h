@@ -53,6 +53,9 @@ enum {
 #define SLAM_REC_LEN 12
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
+/* The context's streams are created at the device's greatest stream priority, so that they get hardware queues of
+ * their own (the HIP runtime pools queues per priority level and shares a pool among all streams of the level);
+ * the environment variable SLAM_AMD_STREAM_PRIORITY=normal|low selects another level. */
 int slam_create(int device, slam_ctx** out);
 void slam_destroy(slam_ctx* ctx);
 const char* slam_last_error(const slam_ctx* ctx); /* ctx may be NULL: text of the last slam_create failure */

@@ -52,12 +52,32 @@ extern "C" int slam_create(int device, slam_ctx** out) {
         return SLAM_EHIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
-    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    // The context's streams are created at the device's greatest stream priority.  The HIP runtime keeps one pool of
+    // hardware queues (4 by default) per priority level and shares a pool's queues among all streams of that level:
+    // at the default level the context's four streams end up sharing queues with each other as soon as the process
+    // has other streams (its null stream, a copy queue, a framework's or a collective library's streams), and steps
+    // meant to overlap run one after the other (measured: 9.5 us per step instead of 6.9).  A level of their own
+    // gives them one hardware queue each whatever else the process did before.  SLAM_AMD_STREAM_PRIORITY=normal|low
+    // chooses another level.
+    int prio_least = 0, prio_greatest = 0;
+    if ((e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess)
+        return fail("hipDeviceGetStreamPriorityRange", e);
+    int prio = prio_greatest;
+    if (const char* want = getenv("SLAM_AMD_STREAM_PRIORITY")) {
+        if (!strcmp(want, "normal")) prio = 0;
+        else if (!strcmp(want, "low")) prio = prio_least;
+        else if (strcmp(want, "high")) {
+            snprintf(g_create_err, sizeof g_create_err, "SLAM_AMD_STREAM_PRIORITY=%s: expected high, normal or low", want);
+            delete ctx;
+            return SLAM_EINVAL;
+        }
+    }
+    if ((e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio)) != hipSuccess)
         return fail("hipStreamCreate", e);
     ctx->stream = ctx->cur = ctx->own_stream;
     ctx->lane_stream[0] = ctx->own_stream;
     for (int l = 1; l < SLAM_LANES; ++l)
-        if ((e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking)) != hipSuccess)
+        if ((e = hipStreamCreateWithPriority(&ctx->lane_stream[l], hipStreamNonBlocking, prio)) != hipSuccess)
             return fail("hipStreamCreate", e);
     if ((e = hipHostMalloc((void**)&ctx->h_small, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
         return fail("hipHostMalloc", e);

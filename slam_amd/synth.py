@@ -175,3 +175,45 @@ def make_feature_pair(n_true, n_clutter=0, flip_bits=20, seed=0, outlier_frac=0.
     truth = np.where(order0 < n_true, where1[np.minimum(order0, n_true + n_clutter - 1)], -1)
     d.update(kp0=kp0[order0], des0=des0[order0], kp1=kp1[order1], des1=des1[order1], truth=truth)
     return d
+
+
+def make_sequence(n_frames, n_landmarks=1500, n_clutter=200, flip_bits=16, seed=0, K=KITTI_K, size=KITTI_SIZE,
+                  noise_px=0.3, step=1.0):
+    """Keypoints and 256-bit descriptors of ``n_frames`` views of one static scene from a camera that drives forward
+    (``step`` units per frame, small rotations): the input of the reference's driver loop (custom_slam.py:203-254)
+    after its ORB calls.  Every frame lists the landmarks it sees (pixel noise ``noise_px``, descriptor = the
+    landmark's with ``flip_bits`` random bits flipped) and ``n_clutter`` unrelated keypoints, in shuffled order.
+    Returns frames [(keypoints (n,2), descriptors (n,32) uint8)], landmark [(n,) landmark id or -1 per keypoint],
+    poses [(4,4) world -> camera, frame 0 = identity], X (landmarks in world = frame-0 coordinates) and K."""
+    rng = np.random.default_rng(seed)
+    w, h = size
+    Kinv = np.linalg.inv(K)
+    uv = np.column_stack([rng.uniform(0, w, n_landmarks), rng.uniform(0, h, n_landmarks), np.ones(n_landmarks)])
+    depth = rng.uniform(8.0 + step * n_frames, 60.0, n_landmarks)
+    X = (uv @ Kinv.T) * depth[:, None]
+    base = rng.integers(0, 2, (n_landmarks, 256), dtype=np.uint8)
+    R, t = np.eye(3), np.zeros(3)
+    frames, landmark, poses = [], [], []
+    for k in range(n_frames):
+        if k > 0:
+            t = t + R @ (step * np.array([rng.normal(0, 0.08), rng.normal(0, 0.03), 1.0]))
+            R = R @ _rotation(rng.normal(size=3), np.deg2rad(1.5) * rng.uniform(0.2, 1.0))
+        pose = np.eye(4)
+        pose[:3, :3] = R.T
+        pose[:3, 3] = -R.T @ t
+        q = (X - t) @ R
+        proj = q @ K.T
+        px = proj[:, :2] / proj[:, 2:3]
+        seen = np.flatnonzero((q[:, 2] > 1.0) & (px[:, 0] >= 0) & (px[:, 0] < w) & (px[:, 1] >= 0) & (px[:, 1] < h))
+        kp = px[seen] + rng.normal(0, noise_px, (len(seen), 2))
+        bits = base[seen].copy()
+        for i in range(len(seen)):
+            bits[i, rng.choice(256, flip_bits, replace=False)] ^= 1
+        kp = np.vstack([kp, np.column_stack([rng.uniform(0, w, n_clutter), rng.uniform(0, h, n_clutter)])])
+        bits = np.vstack([bits, rng.integers(0, 2, (n_clutter, 256), dtype=np.uint8)])
+        ids = np.concatenate([seen, -np.ones(n_clutter, dtype=np.int64)])
+        order = rng.permutation(len(kp))
+        frames.append((np.ascontiguousarray(kp[order]), np.packbits(bits[order], axis=1)))
+        landmark.append(ids[order])
+        poses.append(pose)
+    return {"frames": frames, "landmark": landmark, "poses": poses, "X": X, "K": np.array(K)}

@@ -381,6 +381,39 @@ def gen_config1():
     print("config1: matches", len(m0), buf.getvalue().strip().replace("\n", " | "))
 
 
+def gen_driver():
+    """The reference's own driver object (custom_slam.py:118-254: Slam.find_initial_pose, then Slam.find_next_pose, the
+    two calls its main() makes) run on a synthetic three-frame sequence.  Only the two things OpenCV does for it are
+    replaced, by assignment at run time: compute_orb returns a frame's synthetic keypoints and unpacked descriptor
+    bits, and match_knn (an approximate OpenCV index) calls the reference's own exact match_knn_brute_force.  An
+    "image" is a frame number.  Everything else - matching loop, ratio test, normalisation, both RANSACs, the map
+    lookups by 2D point - is the reference's code, unchanged."""
+    seq = synth.make_sequence(3, n_landmarks=260, n_clutter=60, seed=131, K=synth.REFERENCE_K, size=synth.REFERENCE_SIZE)
+    frames = seq["frames"]
+    sys.modules["cv2"].ORB_create = lambda *a, **k: None
+    custom_slam.compute_orb = lambda img, orb: (np.asarray(frames[img][0]), np.unpackbits(frames[img][1], axis=1))
+    custom_slam.match_knn = lambda d0, d1, num_matches=2: custom_slam.match_knn_brute_force(d0, d1, num_matches)
+    slam = custom_slam.Slam(seq["K"], show_image_keypoints=False, show_3d_visualization=False)
+    buf = io.StringIO()
+    logger.set_log_level("INFO")
+    with contextlib.redirect_stdout(buf):
+        slam.find_initial_pose(0, 1)
+        n_map = len(slam.triangulated_point_lookup[2])
+        latest = np.array(slam.latest_image_2d_points)
+        all_pts = np.array(slam.all_triangulated_points)
+    with contextlib.redirect_stdout(io.StringIO()):       # the tracking loop prints every intermediate matrix
+        logger.set_log_level("WARN")
+        slam.find_next_pose(1, 2)
+    out = {"K": seq["K"], "pose1": slam.camera_poses[1], "pose2": slam.camera_poses[2], "n_poses": len(slam.camera_poses),
+           "n_map_frame2": n_map, "latest_image_2d_points": latest, "all_triangulated_points": all_pts,
+           "true_pose1": seq["poses"][1], "true_pose2": seq["poses"][2], "log": np.array(buf.getvalue())}
+    for k, (kp, des) in enumerate(frames):
+        out[f"kp{k}"], out[f"des{k}"] = kp, des
+    np.savez_compressed(os.path.join(HERE, "driver.npz"), **out)
+    print("driver: map points for frame 2:", n_map, "| poses", len(slam.camera_poses), "|",
+          buf.getvalue().strip().splitlines()[-1])
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -396,4 +429,5 @@ if __name__ == "__main__":
     gen_tracking()
     gen_matching()
     gen_config1()
+    gen_driver()
     print("python", sys.version.split()[0], "numpy", np.__version__)

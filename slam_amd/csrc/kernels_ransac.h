@@ -6,6 +6,12 @@
 #include "kernels_tri.h"  // PairArgs
 #include "linalg.h"
 
+// waves per CU the fused kernel is compiled for when a lane keeps at most four matches (N <= 2048): 40 = five per
+// SIMD = 96 registers.  48 (80 registers) spills 76 bytes per lane inside the solve and makes the kernel 20 % slower
+// (11.8 against 9.5 us at N=2048, H=1000), also for a batch of pairs that fills the chip.
+#ifndef SLAM_SMALL_SHAPE_WAVES
+#define SLAM_SMALL_SHAPE_WAVES 40
+#endif
 namespace slamk {
 
 #ifdef SLAM_STAMPS
@@ -502,7 +508,7 @@ __device__ __forceinline__ void barrier_lds_only() {
 }
 
 template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
-__global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? 48 : 32) / WAVES) void k_ransac(
+__global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32) / WAVES) void k_ransac(
     const double2* __restrict__ p0, const double2* __restrict__ p1, int N, const int32_t* __restrict__ idx_in,
     uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw, int64_t raw_it0, double rcut,
     double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags,

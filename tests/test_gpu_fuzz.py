@@ -1,0 +1,168 @@
+"""Differential runs of the GPU RANSAC against the C restatement on random shapes: number of matches (around every
+boundary of the sampler and of the scoring shapes), number of hypotheses (around the workgroup size of 8), outlier
+share, pixel noise and threshold vary per case.
+
+Exact: per-hypothesis inlier counts, the winner, its mask.  Within tolerance: every hypothesis' F (1e-6 relative
+after sign normalisation; typical agreement is 1e-13, and 1e-8 for the odd sample whose 8 x 9 system is nearly of
+rank 7, where LAPACK's answer moves by as much) and its inlier sum, which may differ by what that difference in F
+explains: |d errsum| <= 2 sqrt(errsum count) C dF + count C^2 dF^2 with C = max |x1||x0| (plus 1e-12 relative).
+A winner that differs only because two hypotheses with equal counts have inlier sums equal within that tolerance is
+the tie the reference itself leaves open (its outcome there depends on the LAPACK build): it shows up on exact data
+(no pixel noise), where the sums are rounding noise of 1e-25; such cases are counted and bounded, not failed.
+tests/fuzz_case.py prints one case in detail."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from slam_amd import _lib, epipolar, logger, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+NS = [8, 9, 12, 40, 85, 86, 200, 511, 512, 513, 1000, 2047, 2048, 2049, 3000, 4096, 4097, 5000, 9000]
+HS = [1, 2, 7, 8, 9, 63, 64, 65, 100, 333, 1000]
+
+
+@pytest.mark.parametrize("seed", (1, 2, 3))
+def test_random_shapes_against_c_restatement(seed):
+    logger.set_log_level("WARN")
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(seed)
+    ties = 0
+    cases = 250
+    for case in range(cases):
+        N = int(rng.choice(NS)) if rng.random() < 0.5 else int(rng.integers(8, 6000))
+        H = int(rng.choice(HS))
+        frac = float(rng.choice([0.0, 0.1, 0.3, 0.5, 0.8]))
+        noise = float(rng.choice([0.0, 0.2, 0.5, 2.0]))
+        thr = float(rng.choice([0.005, 0.005, 1e-4, 0.05]))
+        where = f"seed {seed} case {case}: N={N} H={H} outliers={frac} noise={noise} thr={thr}"
+        d = synth.make_pair(N, frac, seed=1000 * seed + case, noise_px=noise)
+        n0, _ = pipeline.normalize_points(d["pts0"], ctx=ctx)
+        n1, _ = pipeline.normalize_points(d["pts1"], ctx=ctx)
+        g = epipolar.ransac_detailed(n0, n1, H, threshold=thr, per_hypothesis=True, ctx=ctx)
+        o = co.ransac(n0, n1, co.sample(N, g["H"]), thr=thr)
+        assert np.array_equal(g["counts"], o["counts"]), where
+        Fg, Fo = g["F_all"].reshape(-1, 9), o["F"].reshape(-1, 9)
+        sign = np.sign(np.sum(Fg * Fo, axis=1, keepdims=True))
+        dF = np.linalg.norm(Fg * sign - Fo, axis=1) / np.linalg.norm(Fo, axis=1)
+        assert dF.max() <= 1e-6, where
+        C = float(np.max(np.sqrt(1 + np.sum(n0 * n0, axis=1)) * np.sqrt(1 + np.sum(n1 * n1, axis=1))))
+        cnt = o["counts"].astype(np.float64)
+        tol = 2 * np.sqrt(o["errsums"] * cnt) * C * dF + cnt * (C * dF) ** 2 + 1e-12 * o["errsums"] + 1e-300
+        assert np.all(np.abs(g["errsums"] - o["errsums"]) <= tol), where
+        gi, oi = g["best_index"], o["best_index"]
+        if gi != oi:
+            assert o["counts"][gi] == o["counts"][oi], where
+            assert abs(o["errsums"][gi] - o["errsums"][oi]) <= tol[oi] + tol[gi], where
+            ties += 1
+        else:
+            assert np.array_equal(g["best_mask"], o["best_mask"]), where
+            assert g["best_count"] == o["best_count"], where
+    assert ties <= cases // 8, f"{ties} of {cases} winners decided by rounding"
+
+
+@pytest.mark.parametrize("seed", (11, 12))
+def test_random_descriptor_sets_against_c_restatement(seed):
+    """Matcher: 2-NN indices and distances, and the kept matches, exact on random set sizes (1 .. 1500 per side,
+    around the 64-query and 256-query tile edges), with few distinct descriptors in a third of the cases (ties)."""
+    from slam_amd import matching
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(seed)
+    edges = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025]
+    for case in range(120):
+        n0 = int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, 1500))
+        n1 = int(rng.choice(edges[1:])) if rng.random() < 0.5 else int(rng.integers(2, 1500))
+        where = f"seed {seed} case {case}: n0={n0} n1={n1}"
+        if case % 3 == 0:
+            base = rng.integers(0, 256, (int(rng.integers(1, 9)), 32), dtype=np.uint8)
+            d0, d1 = base[rng.integers(0, len(base), n0)], base[rng.integers(0, len(base), n1)]
+        else:
+            d0 = rng.integers(0, 256, (n0, 32), dtype=np.uint8)
+            d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+            for q in range(0, min(n0, n1), 2):          # plant near copies so that the ratio test keeps some
+                d1[q] = d0[q]
+                d1[q, int(rng.integers(0, 32))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        p0, p1 = rng.uniform(0, 1000, (n0, 2)), rng.uniform(0, 1000, (n1, 2))
+        gi, gd = matching.knn(d0, d1, 2, ctx=ctx)
+        oi, od = co.match_knn(d0, d1, 2)
+        assert np.array_equal(gd, od), where
+        assert np.array_equal(gi, oi), where
+        m0, m1 = matching.matches_between_keypoints(p0, d0, p1, d1, ctx=ctx)
+        r0, r1 = co.select_matches(p0, p1, oi, od)
+        assert np.array_equal(m0, r0) and np.array_equal(m1, r1), where
+
+
+@pytest.mark.parametrize("seed", (21, 22))
+def test_random_tracking_steps_against_c_restatement(seed):
+    """Tracking step on random sizes: 6 .. 400 matches with a known position (the six-point sampler's pool and set
+    paths, fewer hypotheses than iterations when C(M,6) is small), 1 .. 100 iterations, 0 .. 50 % wrong matches.
+    Counts are compared exactly except where a triangulated point sits within rounding of a camera plane (the
+    hypothesis' count may then differ by the points that do; bounded at one hypothesis in a thousand)."""
+    from conftest import rel_err
+    from slam_amd import triangulation
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(seed)
+    off = total = 0
+    for case in range(60):
+        M = int(rng.choice([6, 7, 8, 20, 21, 22, 64, 100, 300])) if rng.random() < 0.6 else int(rng.integers(6, 400))
+        iters = int(rng.choice([1, 2, 7, 33, 100]))
+        frac = float(rng.choice([0.0, 0.2, 0.5]))
+        where = f"seed {seed} case {case}: M={M} iterations={iters} wrong={frac}"
+        d = synth.make_track(M, M + int(rng.integers(0, 500)), frac, 5000 * seed + case)
+        r = triangulation.track_pose_detailed(d["previous_pose"], d["prev_known"], d["next_known"], d["X_known"],
+                                              d["prev_all"], d["next_all"], d["K"], iters, ctx)
+        H = len(r["counts"])
+        want = co.tracking_ransac(d["previous_pose"], d["prev_known"], d["next_known"], d["X_known"], d["K"],
+                                  co.sample(M, H, k=6))
+        same = r["counts"] == want["counts"]
+        off += int(np.sum(~same))
+        total += H
+        assert np.all(np.abs(r["counts"] - want["counts"]) <= 2), where
+        if same.all():
+            assert np.max(np.abs(r["errs"][same] / want["errs"][same] - 1)) < 1e-5, where
+            gi, oi = r["best_index"], want["best_index"]
+            if gi != oi:
+                # small M: two iterations drew the same six matches in another order, their errors differ in the
+                # last bits only and the strict comparison (src/triangulation.py:172-173) is decided by rounding
+                assert want["counts"][gi] == want["counts"][oi], where
+                assert abs(want["errs"][gi] / want["errs"][oi] - 1) < 1e-9, where
+            assert rel_err(r["pose"], want["poses"][gi]) < 1e-6, where
+    assert off * 1000 <= total, f"{off} of {total} hypothesis counts differ"
+
+
+@pytest.mark.parametrize("seed", (31,))
+def test_random_pairs_whole_initialisation_against_c_restatement(seed):
+    """The whole two-view initialisation (normalise, RANSAC, denormalise, F->E, four candidates, selection, z > 0
+    flags) on random pairs, single calls and one ragged batch, against the chain of C restatements."""
+    from _oracle_backend import OracleBackend
+    from conftest import rel_err
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(seed)
+    oracle = OracleBackend(iterations=200)
+    pairs, wants = [], []
+    for case in range(40):
+        N = int(rng.choice([8, 9, 16, 85, 86, 512, 513, 2048, 2049])) if rng.random() < 0.5 else int(rng.integers(8, 3000))
+        frac = float(rng.choice([0.0, 0.2, 0.5]))
+        d = synth.make_pair(N, frac, seed=7000 * seed + case, noise_px=float(rng.choice([0.2, 0.5, 1.0])))
+        pairs.append((d["pts0"], d["pts1"]))
+        wants.append(oracle.initialise(d["pts0"], d["pts1"], d["K"]))
+    K = synth.KITTI_K
+    singles = [pipeline.initialise_pair(p0, p1, K, 200, ctx=ctx) for p0, p1 in pairs]
+    batch = pipeline.initialise_pairs(pairs, K, 200, ctx=ctx)
+    checked = 0
+    for case, (r, b, (pose, X, good)) in enumerate(zip(singles, batch, wants)):
+        where = f"seed {seed} case {case}: N={len(pairs[case][0])}"
+        for key in ("F", "E", "pose", "X", "mask", "record", "counts"):      # the batch is bit-identical to single calls
+            assert np.array_equal(np.asarray(r[key]), np.asarray(b[key]), equal_nan=True), (where, key)
+        c4 = np.sort(r["counts"])
+        if c4[-1] == c4[-2]:
+            continue                                     # two candidates tie on the cheirality count: order-dependent
+        assert rel_err(r["pose"], pose) < 1e-6, where
+        ok = np.isfinite(X).all(axis=1) & np.isfinite(r["X"]).all(axis=1)
+        scale = np.maximum(np.abs(X[ok]), 1e-3 * np.abs(X[ok]).max(axis=1, keepdims=True))
+        # 3D points to 1e-5 relative, except points that the degenerate geometry puts near infinity (|X| > 1e6 units)
+        near = np.abs(X[ok]).max(axis=1) < 1e6
+        assert np.max(np.abs(r["X"][ok][near] - X[ok][near]) / scale[near], initial=0.0) < 1e-5, where
+        assert np.mean(r["mask"][ok][near] == good[ok][near]) == 1.0, where
+        checked += 1
+    assert checked >= 30

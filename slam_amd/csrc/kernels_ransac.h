@@ -23,8 +23,16 @@ __device__ long long g_stamps[4096 * 8];
         if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (slot)] = clock64(); \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     } while (0)
+// the selection kernel's stamps go to the last row
+#define SLAM_STAMP_SELECT(slot)                                                       \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[4095 * 8 + (slot)] = clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
 #else
 #define SLAM_STAMP(slot) do { } while (0)
+#define SLAM_STAMP_SELECT(slot) do { } while (0)
 #endif
 
 
@@ -590,9 +598,29 @@ __device__ __forceinline__ bool better(const Best& x, const Best& y) {  // x bea
     return x.index < y.index;
 }
 
+// best of the 16 lanes of a row, on every lane of the row: four DPP exchanges (lane^1, lane^2, the mirrored halves
+// of 8 and of 16 lanes), no LDS traffic.  The relation is a total order, so the pairing does not matter.
+template <int CTRL>
+__device__ __forceinline__ Best best_with_dpp_partner(const Best& b) {
+    Best o;
+    o.count = dpp_i32<CTRL>(b.count);
+    o.index = dpp_i32<CTRL>(b.index);
+    o.errsum = dpp_f64<CTRL>(b.errsum);
+    return better(o, b) ? o : b;
+}
+
+__device__ __forceinline__ Best row_best(Best b) {
+    b = best_with_dpp_partner<0xB1>(b);   // quad_perm [1,0,3,2]
+    b = best_with_dpp_partner<0x4E>(b);   // quad_perm [2,3,0,1]
+    b = best_with_dpp_partner<0x141>(b);  // row_half_mirror
+    b = best_with_dpp_partner<0x140>(b);  // row_mirror
+    return b;
+}
+
 __device__ __forceinline__ Best wave_best(Best b) {
+    b = row_best(b);
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
+    for (int m = 16; m < 64; m <<= 1) {
         Best o;
         o.count = __shfl_xor(b.count, m, 64);
         o.index = __shfl_xor(b.index, m, 64);
@@ -630,8 +658,12 @@ __global__ __launch_bounds__(1024) void k_select_partial(const int32_t* __restri
     }
 }
 
+// threads of a selection workgroup (and matches it flags per pass)
+#ifndef SLAM_SELECT_THREADS
+#define SLAM_SELECT_THREADS 1024
+#endif
 template <bool SAMPSON>
-__global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
+__global__ __launch_bounds__(SLAM_SELECT_THREADS) void k_select(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
                                                  const int32_t* __restrict__ index_of,  // NULL: entry h is hypothesis h
                                                  const double* __restrict__ Fall, int H, int64_t it0,
                                                  const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
@@ -641,29 +673,48 @@ __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ cou
         const PairArgs& a = batch[blockIdx.y];
         counts = a.counts; errsums = a.errsums; Fall = a.F_all; H = a.H; p0 = a.n0; p1 = a.n1; N = a.N; record = a.record;
     }
-    __shared__ Best s_best[16];
+    constexpr int T = SLAM_SELECT_THREADS, W = T / 64;
+    static_assert(W == 4 || W == 16, "the fold below handles 4 or 16 wave winners");
+    __shared__ Best s_best[W];
     const int tid = threadIdx.x;
-    // the winner's mask needs every match: fetch this thread's first matches while the reduction runs
-    const int i0 = tid < N ? tid : N - 1;
-    const double2 a_first = p0[i0], b_first = p1[i0];
+    SLAM_STAMP_SELECT(0);
+    // The winner's mask needs every match: the grid's workgroups share the matches (workgroup x takes matches
+    // x*T + tid, then strides by the grid), each finds the winner for itself - the reduction reads 12 bytes per
+    // hypothesis, the mask 32 bytes per match through one CU's memory pipeline - and fetches its first match while
+    // the reduction runs.  Workgroup 0 writes the record.
+    const int i_first = (int)blockIdx.x * T + tid;
+    const int stride = (int)gridDim.x * T;
+    const int i_pre = i_first < N ? i_first : N - 1;
+    const double2 a_pre = p0[i_pre], b_pre = p1[i_pre];
+    // scan: four entries per thread and pass, their loads issued together (clamped, so that they need no branch)
     Best b{-1, 0x7fffffff, 0.0};
-    for (int h = tid; h < H; h += 1024) {
-        const Best c{counts[h], index_of ? index_of[h] : h, errsums[h]};
-        if (better(c, b)) b = c;
+    for (int h0 = tid; h0 < H; h0 += 4 * T) {
+        Best c[4];
+        bool real[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = h0 + k * T;
+            real[k] = h < H;
+            const int hh = real[k] ? h : H - 1;
+            c[k] = Best{counts[hh], index_of ? index_of[hh] : hh, errsums[hh]};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (real[k] && better(c[k], b)) b = c[k];
     }
+    SLAM_STAMP_SELECT(1);
     b = wave_best(b);
+    SLAM_STAMP_SELECT(2);
     if ((tid & 63) == 0) s_best[tid >> 6] = b;
     __syncthreads();
-    Best w = s_best[0];
-#pragma unroll
-    for (int q = 1; q < 16; ++q) {
-        const Best o = s_best[q];
-        if (better(o, w)) w = o;
-    }
+    SLAM_STAMP_SELECT(3);
+    // every row of 16 lanes folds the wave winners the same way (lane l starts from winner l mod W): all lanes end with the same winner
+    const Best w = row_best(s_best[tid & (W - 1)]);
+    SLAM_STAMP_SELECT(4);
     const double* F = Fall + (size_t)w.index * 9;
     const double f00 = F[0], f01 = F[1], f02 = F[2], f10 = F[3], f11 = F[4], f12 = F[5], f20 = F[6], f21 = F[7],
                  f22 = F[8];
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.x == 0) {
         record[SLAM_REC_COUNT] = (double)w.count;
         record[SLAM_REC_ERRSUM] = w.errsum;
         record[SLAM_REC_INDEX] = (double)(it0 + w.index);
@@ -672,8 +723,7 @@ __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ cou
         record[SLAM_REC_F + 6] = f20; record[SLAM_REC_F + 7] = f21; record[SLAM_REC_F + 8] = f22;
     }
     if (mask) {
-        for (int i = tid; i < N; i += 1024) {
-            const double2 a = (i == tid) ? a_first : p0[i], bb = (i == tid) ? b_first : p1[i];
+        auto flag = [&](int i, const double2 a, const double2 bb) {
             const double l0 = fma(bb.x, f00, fma(bb.y, f10, f20));
             const double l1 = fma(bb.x, f01, fma(bb.y, f11, f21));
             const double l2 = fma(bb.x, f02, fma(bb.y, f12, f22));
@@ -682,8 +732,11 @@ __global__ __launch_bounds__(1024) void k_select(const int32_t* __restrict__ cou
                 mask[i] = (sampson_error(r, l0, l1, a.x, a.y, f00, f01, f02, f10, f11, f12) < rcut) ? 1 : 0;
             else
                 mask[i] = (fabs(r) < rcut) ? 1 : 0;  // same predicate as the scoring kernels
-        }
+        };
+        if (i_first < N) flag(i_first, a_pre, b_pre);
+        for (int i = i_first + stride; i < N; i += stride) flag(i, p0[i], p1[i]);
     }
+    SLAM_STAMP_SELECT(5);
 }
 
 }  // namespace slamk

@@ -405,6 +405,11 @@ static int launch_ransac(slam_ctx* ctx, const double2* p0, const double2* p1, in
 
 static constexpr int SLAM_MAX_MATCHES = 1 << 27;
 
+// workgroups of the selection kernel: one per SLAM_SELECT_THREADS matches when it also writes the winner's mask (at most 64)
+static dim3 select_grid(int N, const void* mask) {
+    return dim3(mask ? (unsigned)std::min((N + SLAM_SELECT_THREADS - 1) / SLAM_SELECT_THREADS, 64) : 1u);
+}
+
 static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                           int sampler, uint64_t seed, int64_t it0, int H, double thr, double* d_record,
                           uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all) {
@@ -449,10 +454,10 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
         sel_counts = pc; sel_errsums = pe; sel_index = pi; sel_H = parts;
     }
     if (ctx->sampson)
-        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<true>, dim3(1), dim3(1024), 0, sel_counts, sel_errsums, sel_index,
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<true>, select_grid(N, d_mask), dim3(SLAM_SELECT_THREADS), 0, sel_counts, sel_errsums, sel_index,
                              (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask, (const PairArgs*)nullptr));
     else
-        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1), dim3(1024), 0, sel_counts, sel_errsums, sel_index,
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, select_grid(N, d_mask), dim3(SLAM_SELECT_THREADS), 0, sel_counts, sel_errsums, sel_index,
                              (const double*)d_F_all, sel_H, it0, p0, p1, N, thr, d_record, d_mask, (const PairArgs*)nullptr));
     return SLAM_OK;
 }
@@ -627,12 +632,12 @@ extern "C" int slam_ransac_f_adaptive(slam_ctx* ctx, const double* p0, const dou
         const double cut = ctx->sampson ? threshold : square_cutoff(threshold);
         const double2 *q0 = (const double2*)d0, *q1 = (const double2*)d1;
         if (ctx->sampson)
-            SLAM_TRY(slam_launch(ctx, -1, k_select<true>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
+            SLAM_TRY(slam_launch(ctx, -1, k_select<true>, select_grid(N, ctx->mask.p), dim3(SLAM_SELECT_THREADS), 0, (const int32_t*)ctx->counts.p,
                                  (const double*)ctx->errsums.p, (const int32_t*)nullptr, (const double*)dF, 1,
                                  (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
                                  cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p, (const PairArgs*)nullptr));
         else
-            SLAM_TRY(slam_launch(ctx, -1, k_select<false>, dim3(1), dim3(1024), 0, (const int32_t*)ctx->counts.p,
+            SLAM_TRY(slam_launch(ctx, -1, k_select<false>, select_grid(N, ctx->mask.p), dim3(SLAM_SELECT_THREADS), 0, (const int32_t*)ctx->counts.p,
                                  (const double*)ctx->errsums.p, (const int32_t*)nullptr, (const double*)dF, 1,
                                  (int64_t)best[SLAM_REC_INDEX], q0, q1, N,
                                  cut, (double*)ctx->record.p, (uint8_t*)ctx->mask.p, (const PairArgs*)nullptr));
@@ -1007,7 +1012,7 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
         else SLAM_BATCH_RANSAC(8);
 #undef SLAM_BATCH_RANSAC
     }
-    SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1, P), dim3(1024), 0, (const int32_t*)nullptr,
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select<false>, dim3(1, P), dim3(SLAM_SELECT_THREADS), 0, (const int32_t*)nullptr,
                          (const double*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, 0, (int64_t)0,
                          (const double2*)nullptr, (const double2*)nullptr, 0, rcut, (double*)nullptr, (uint8_t*)nullptr, all));
     SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1, P), dim3(64), 0, kk, (const double*)nullptr, (double*)nullptr,

@@ -27,10 +27,11 @@ torch.cuda.synchronize()
 for _ in range(20):
     ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N, None, 0, _lib.SEED_BASE, 0, H, 0.005,
                                     d_rec.data_ptr(), None, None, None, None))
-nb = min(4096, (H + 7) // 8)
-out = np.zeros(nb * 8, dtype=np.int64)
+nb = min(4095, (H + 7) // 8)
+full = np.zeros(4096 * 8, dtype=np.int64)
 lib.slam_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-ctx.check(lib.slam_debug_stamps(ctx.handle, out.ctypes.data, nb * 8))
+ctx.check(lib.slam_debug_stamps(ctx.handle, full.ctypes.data, 4096 * 8))
+out = full[:nb * 8]
 raw = out.reshape(nb, 8).astype(np.float64)
 # slots in program order: 0 start, 1 drawn, 7 null vector found, 2 solved, 3 past the barrier, 4 scored,
 # 6 wave totals written, 5 past the last barrier
@@ -45,3 +46,6 @@ for i, nme in enumerate(names):
     print(f"  {nme:8s} median {q[0]:9.0f}  90% {q[1]:9.0f}  99% {q[2]:9.0f}  max {d[:, i].max():9.0f}")
 tot = st[:, -1] - st[:, 0]
 print(f"  workgroup total median {np.median(tot):.0f}  max {tot.max():.0f}; first start to last end {st[:, -1].max() - t0:.0f} cycles")
+sel = full[4095 * 8:4095 * 8 + 6].astype(np.float64)
+print("selection kernel (one workgroup), cycles: " + ", ".join(f"{n} {d:.0f}" for n, d in zip(
+    ["loads+scan", "wave reduction", "barrier", "fold of 16", "F load + mask"], np.diff(sel))) + f"; total {sel[5] - sel[0]:.0f}")

@@ -21,7 +21,7 @@ int main() {
     hipDeviceGetStreamPriorityRange(&lo, &hi);
     double* d; hipMalloc(&d, 8);
     struct Shape { int grid, block, iters; };
-    const Shape shapes[] = {{256, 512, 600}, {128, 512, 600}, {512, 256, 600}, {256, 256, 600}, {256, 64, 600}, {2048, 64, 600},
+    const Shape shapes[] = {{256, 512, 0}, {128, 512, 0}, {256, 64, 0}, {2048, 64, 0}, {4096, 512, 0}, {256, 512, 600}, {128, 512, 600}, {512, 256, 600}, {256, 256, 600}, {256, 64, 600}, {2048, 64, 600},
                             {256, 512, 60}, {256, 512, 2400}, {128, 512, 2400}, {256, 1024, 600}};
     for (const Shape& sh : shapes) {
         const int T = 2, L = 2;
@@ -42,6 +42,31 @@ int main() {
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("grid %4d x %4d threads, %4d dependent FMAs (%.1f us of work per wave): %.2f us per launch with 2 threads x 2 streams\n",
                sh.grid, sh.block, sh.iters, sh.iters * 9.0 / 2350.0, dt / (launches * T) * 1e6);
+        for (auto& s : st) hipStreamDestroy(s);
+    }
+    // the same busy kernel on 6 streams from 3 threads: all at one priority, or two per priority level
+    for (int mixed : {0, 1}) {
+        const int T = 3, L = 2;
+        std::vector<hipStream_t> st(T * L);
+        for (int i = 0; i < T * L; ++i) {
+            const int prio = mixed ? (i / 2 == 0 ? hi : (i / 2 == 1 ? 0 : lo)) : hi;
+            hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, prio);
+        }
+        std::atomic<int> go{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                while (!go.load()) {}
+                for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_busy, dim3(256), dim3(512), 0, st[t * L + i % L], d, 600);
+                for (int l = 0; l < L; ++l) hipStreamSynchronize(st[t * L + l]);
+            });
+        const auto t0 = std::chrono::steady_clock::now();
+        go.store(1);
+        for (auto& x : th) x.join();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("busy 256 x 512 kernel, 3 threads x 2 streams, %s: %.2f us per launch\n",
+               mixed ? "one thread per priority level (greatest, default, least)" : "all streams at the greatest priority",
+               dt / (launches * T) * 1e6);
         for (auto& s : st) hipStreamDestroy(s);
     }
     for (int busy : {0, 1})

@@ -17,22 +17,56 @@ namespace slamk {
 #ifdef SLAM_STAMPS
 // diagnostic build only: shader-clock stamps of workgroup phases, read back by slam_debug_stamps()
 __device__ long long g_stamps[4096 * 8];
+#ifdef SLAM_NO_PHASE_STAMPS  // log-only diagnostic build: the workgroup log below without the phase stamps' stores
+#define SLAM_STAMP(slot) do { } while (0)
+#else
 #define SLAM_STAMP(slot)                                                                        \
     do {                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                      \
         if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (slot)] = clock64(); \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     } while (0)
+#endif
+// Log of workgroup lifetimes across launches (constant 100 MHz clock, comparable between CUs and launches): while
+// g_wg_log_on is set, every workgroup of the fused kernel appends {tag of its launch (bits of its F pointer and its
+// first iteration), workgroup index, XCC/CU id, lifetime in shader cycles, end on the constant clock (read once, at
+// the very end: that read takes about a microsecond)}; read back by slam_debug_wg_log().
+#define SLAM_WG_LOG_MAX (1 << 17)
+__device__ unsigned int g_wg_log_on, g_wg_log_n;
+__device__ long long g_wg_log[SLAM_WG_LOG_MAX * 4];
+#define SLAM_WG_LOG_BEGIN() const long long wg_log_t0_ = clock64()  /* shader clock: cheap to read */
+#define SLAM_WG_LOG_END(tag)                                                                          \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && g_wg_log_on) {                                                        \
+            const unsigned int slot_ = atomicAdd(&g_wg_log_n, 1u);                                    \
+            if (slot_ < SLAM_WG_LOG_MAX) {                                                            \
+                unsigned int hw_;                                                                     \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                     \
+                unsigned int xcc_;                                                                    \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                   \
+                g_wg_log[4 * slot_ + 0] = (long long)(tag);                                           \
+                g_wg_log[4 * slot_ + 1] = ((long long)blockIdx.x << 32) | ((xcc_ & 0xf) << 16) | (hw_ & 0xffff); \
+                g_wg_log[4 * slot_ + 2] = clock64() - wg_log_t0_; /* lifetime in shader cycles */      \
+                g_wg_log[4 * slot_ + 3] = wall_clock64();         /* end, constant 100 MHz clock */   \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
 // the selection kernel's stamps go to the last row
+#ifdef SLAM_NO_PHASE_STAMPS
+#define SLAM_STAMP_SELECT(slot) do { } while (0)
+#else
 #define SLAM_STAMP_SELECT(slot)                                                       \
     do {                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                            \
         if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[4095 * 8 + (slot)] = clock64(); \
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
+#endif
 #else
 #define SLAM_STAMP(slot) do { } while (0)
 #define SLAM_STAMP_SELECT(slot) do { } while (0)
+#define SLAM_WG_LOG_BEGIN() do { } while (0)
+#define SLAM_WG_LOG_END(tag) do { } while (0)
 #endif
 
 
@@ -537,6 +571,7 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the branches on it below are scalar branches
     const int h0 = blockIdx.x * HB;
     SLAM_STAMP(0);
+    SLAM_WG_LOG_BEGIN();
     const int hs = min(h0 + min(wave, HB - 1), H - 1);  // surplus waves redo a hypothesis; their results are dropped
     uint32_t word = 0;
     if (SAMPLER == SLAM_SAMPLER_CPYTHON) word = raw[(size_t)(it0 + hs - raw_it0) * SLAM_RAW_WORDS + lane];
@@ -578,6 +613,7 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
     barrier_lds_only();
     SLAM_STAMP(3);
     score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
+    SLAM_WG_LOG_END((unsigned long long)(uintptr_t)Fout);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1347,6 +1347,23 @@ extern "C" int slam_frame_pair(slam_ctx* ctx, const uint8_t* des0, const double*
 
 #ifdef SLAM_STAMPS
 // diagnostic build only (never declared in the public header)
+// starts (on != 0, log cleared) or stops the workgroup log; when stopping, copies up to n entries of four values to
+// out and returns their number through *count
+extern "C" int slam_debug_wg_log(slam_ctx* ctx, int on, long long* out, int n, int* count) {
+    SLAM_TRY(slam_sync_all(ctx));
+    unsigned int flag = on ? 1u : 0u, zero = 0u;
+    if (on) SLAM_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(slamk::g_wg_log_n), &zero, sizeof zero));
+    SLAM_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(slamk::g_wg_log_on), &flag, sizeof flag));
+    if (!on && out && count) {
+        unsigned int have = 0;
+        SLAM_HIP(ctx, hipMemcpyFromSymbol(&have, HIP_SYMBOL(slamk::g_wg_log_n), sizeof have));
+        have = std::min<unsigned int>(have, std::min<unsigned int>((unsigned int)n, SLAM_WG_LOG_MAX));
+        SLAM_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(slamk::g_wg_log), sizeof(long long) * 4 * (size_t)have));
+        *count = (int)have;
+    }
+    return SLAM_OK;
+}
+
 extern "C" int slam_debug_stamps(slam_ctx* ctx, long long* out, int n) {
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SLAM_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(slamk::g_stamps), sizeof(long long) * (size_t)n));

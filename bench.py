@@ -144,11 +144,18 @@ def main():
         ctx.check(lib.slam_synchronize(ctx.handle))
     for _ in range(args.warmup):
         step()
+    # the timed loop issues exactly K steps, one library call each, cycling over the LANES prepared calls; the list is
+    # laid out beforehand so that the loop itself is nothing but the calls
+    timed = [jobs[(calls[0] + i) % LANES] for i in range(args.steps)]
+    failed = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for job in timed:
+        failed |= run(job)
     dt = stop_clock() - t0
+    calls[0] += args.steps
+    if failed:
+        ctx.check(-2)  # raises with the library's message for the last failure
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -5,6 +5,9 @@
 
 #include <type_traits>
 
+#ifndef SLAM_CUBIC_NEWTON_STEPS
+#define SLAM_CUBIC_NEWTON_STEPS 9
+#endif
 #ifndef SLAM_RANK2_TOL
 #define SLAM_RANK2_TOL 1e-15
 #endif
@@ -120,6 +123,57 @@ __device__ __forceinline__ void jacobi_sweeps(double (&A)[M][N], double (&V)[N][
         // done.  Otherwise the other pair goes FIRST: with columns 0 and 1 orthogonal, rotating each against the last
         // column is a proper cyclic sweep whose errors square; with them oblique, the second rotation re-opens the
         // first pair's angle to first order and costs another rotating sweep.
+        // Before any rotation: when the last column is off by a tiny angle only (the usual state after a warm start),
+        // one joint first-order step makes it orthogonal to both other columns at once.  With a_j = |b_j|^2 and
+        // c_ij = b_i . b_j, the step b2 -= t0 b0 + t1 b1, b0 += t0 b2, b1 += t1 b2 (the same on V) needs
+        //   t0 (a0 - a2) + t1 c01 = c02,   t0 c01 + t1 (a1 - a2) = c12,
+        // which does not ask for columns 0 and 1 to be orthogonal, and leaves errors of second order: it is taken
+        // when |t0|, |t1| <= 1e-8 (then t^2 is below rounding).  Every lane decides for itself; the sweeps below
+        // start with a look at the result and end at once for a lane that is done.
+        {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, c01 = 0.0, c02 = 0.0, c12 = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                a0 = fma(A[i][0], A[i][0], a0);
+                a1 = fma(A[i][1], A[i][1], a1);
+                a2 = fma(A[i][2], A[i][2], a2);
+                c01 = fma(A[i][0], A[i][1], c01);
+                c02 = fma(A[i][0], A[i][2], c02);
+                c12 = fma(A[i][1], A[i][2], c12);
+            }
+            const bool need0 = (a0 > floor2) && (a2 > floor2) && (c02 * c02 > 1e-30 * (a0 * a2)) && (fabs(c02) > angle_tol * fabs(a0 - a2));
+            const bool need1 = (a1 > floor2) && (a2 > floor2) && (c12 * c12 > 1e-30 * (a1 * a2)) && (fabs(c12) > angle_tol * fabs(a1 - a2));
+            if (!__any(need0 || need1 || full)) return;
+            const double d0 = a0 - a2, d1 = a1 - a2;
+            const double det = fma(d0, d1, -c01 * c01);
+            const double inv = fast_rcp(det);
+            double t0 = fma(c02, d1, -c12 * c01) * inv, t1 = fma(c12, d0, -c02 * c01) * inv;
+            const bool tiny = (need0 || need1) && !full && det > 0.0 && fabs(t0) <= 1e-8 && fabs(t1) <= 1e-8;
+#if defined(SLAM_STAMPS) && defined(SLAM_COUNT_SWEEPS)
+            if (M == 3 && (need0 || need1) && !tiny) {  // per lane: why the first-order step was not taken
+                const double tm = fmax(fabs(t0), fabs(t1));
+                atomicAdd(&g_dbg[!(det > 0.0) ? 3 : (tm <= 1e-4 ? 1 : 2)], 1ull);
+            }
+#endif
+            if (__any(tiny)) {
+                t0 = tiny ? t0 : 0.0;  // other lanes: an exact no-op
+                t1 = tiny ? t1 : 0.0;
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const double x0 = A[i][0], x1 = A[i][1], x2 = A[i][2];
+                    A[i][2] = fma(-t1, x1, fma(-t0, x0, x2));
+                    A[i][0] = fma(t0, x2, x0);
+                    A[i][1] = fma(t1, x2, x1);
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double x0 = V[i][0], x1 = V[i][1], x2 = V[i][2];
+                    V[i][2] = fma(-t1, x1, fma(-t0, x0, x2));
+                    V[i][0] = fma(t0, x2, x0);
+                    V[i][1] = fma(t1, x2, x1);
+                }
+            }
+        }
         bool full_active = full;
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             if (M == 3) SLAM_DBG_ADD(4, 1);
@@ -329,7 +383,7 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
     const double c0 = m00 * (m11 * m22 - m12 * m12) - m01 * (m01 * m22 - m12 * m02) + m02 * (m01 * m12 - m11 * m02);
     double lam = 0.0;
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < SLAM_CUBIC_NEWTON_STEPS; ++it) {
         const double p = fma(fma(c2 - lam, lam, -c1), lam, c0);
         const double dp = fma(fma(-3.0, lam, c2 + c2), lam, -c1);
         lam = fma(-p, __builtin_amdgcn_rcp(dp), lam);  // an approximate reciprocal is enough: the iteration self-corrects
@@ -369,16 +423,13 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
     // only v3 enters the projection f (I - v3 v3^T): the third column alone has to converge (lanes without a usable
     // estimate converge every pair and pick the smallest column below)
     SLAM_DBG_ADD(0, 1);
-    if (!usable) SLAM_DBG_ADD(1, 1);
     jacobi_sweeps<3, 3, true>(B, V, 30, SLAM_RANK2_TOL, !usable);
     double n2[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];
     // ||f v|| >= sigma_3 for every unit v, so a converged third column can never be longer than another column;
     // if it is, the start was poor and the third column settled on the wrong singular vector: converge every pair
-    if (n2[2] > n2[0] || n2[2] > n2[1]) SLAM_DBG_ADD(2, 1);
     if (__any(n2[2] > n2[0] || n2[2] > n2[1])) {
-        SLAM_DBG_ADD(3, 1);
         jacobi_sweeps<3, 3, false>(B, V, 30, 1e-15);
 #pragma unroll
         for (int j = 0; j < 3; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j];

@@ -1369,7 +1369,7 @@ extern "C" int slam_debug_stamps(slam_ctx* ctx, long long* out, int n) {
     SLAM_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(slamk::g_stamps), sizeof(long long) * (size_t)n));
     unsigned long long dbg[8];
     SLAM_HIP(ctx, hipMemcpyFromSymbol(dbg, HIP_SYMBOL(slamk::g_dbg), sizeof dbg));
-    fprintf(stderr, "dbg (per wave): projections %llu unusable starts %llu wrong column %llu safety net %llu sweeps %llu; left after 1/2/3+ sweeps %llu %llu %llu\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+    fprintf(stderr, "dbg (per wave): projections %llu; (per lane) first-order step refused with angle <= 1e-4: %llu, larger: %llu, bad determinant: %llu; (per wave) sweeps %llu; left after 1/2/3+ sweeps %llu %llu %llu\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
     return SLAM_OK;
 }
 #endif

@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libslam_amd_stamps.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("SLAM_STAMPS_LIB", "libslam_amd_stamps.so"))
 import torch  # noqa: E402
 from slam_amd import pipeline, synth  # noqa: E402
 

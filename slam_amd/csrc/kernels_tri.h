@@ -5,6 +5,9 @@
 
 #include "linalg.h"
 
+#ifndef SLAM_TRI_ANGLE_TOL
+#define SLAM_TRI_ANGLE_TOL 1e-12
+#endif
 namespace slamk {
 
 // Layout of the per-context "pose work" block (float64 words) shared by the kernels below.
@@ -58,7 +61,7 @@ __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, c
         for (int j = 0; j < 4; ++j) D[i][j] *= im[j];
     // polished until further rotations would turn y by less than 1e-12 rad (the points are compared to 1e-5)
     double yv[4];
-    least_right_vector_4x4(D, 1e-12, yv);
+    least_right_vector_4x4(D, SLAM_TRI_ANGLE_TOL, yv);
     double Y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Y[i] = m[i] * yv[i];

@@ -8,6 +8,9 @@
 #ifndef SLAM_CUBIC_NEWTON_STEPS
 #define SLAM_CUBIC_NEWTON_STEPS 9
 #endif
+#ifndef SLAM_QUARTIC_NEWTON_STEPS
+#define SLAM_QUARTIC_NEWTON_STEPS 8
+#endif
 #ifndef SLAM_RANK2_TOL
 #define SLAM_RANK2_TOL 1e-15
 #endif
@@ -492,7 +495,7 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
     const double k3 = g[0][0] + g[1][1] + g[2][2] + g[3][3];
     double lam = 0.0;
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < SLAM_QUARTIC_NEWTON_STEPS; ++it) {
         const double p = fma(fma(fma(lam - k3, lam, k2), lam, -k1), lam, k0);
         const double dp = fma(fma(fma(4.0, lam, -3.0 * k3), lam, k2 + k2), lam, -k1);
         lam = fma(-p, __builtin_amdgcn_rcp(dp), lam);  // approximate reciprocal: the iteration self-corrects

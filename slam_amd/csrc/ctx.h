@@ -65,6 +65,10 @@ struct slam_ctx {
     // pinned host staging for small results
     double* h_small = nullptr;  // 1024 doubles
     int32_t* h_flags = nullptr;
+    // pinned staging area of the host entry points (uploads of the match lists, downloads of mask and record): one
+    // copy through it replaces several copies from and to pageable memory, each of which the runtime stages by itself
+    char* h_stage = nullptr;
+    size_t h_stage_cap = 0;
 
     bool profiling = false;
     slam_prof prof;

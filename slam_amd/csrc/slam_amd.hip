@@ -117,6 +117,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->prof.created)
         for (int i = 0; i < slam_prof::kMax; ++i) {
             (void)hipEventDestroy(ctx->prof.start[i]);
@@ -528,12 +529,37 @@ extern "C" int slam_job_run(slam_job* j) {
 
 extern "C" void slam_job_destroy(slam_job* j) { delete j; }
 
-// stage two (N,2) point arrays contiguously in ctx->pts; returns device pointers
+// pinned staging area of at least `bytes` (nullptr above SLAM_STAGE_MAX: such transfers go directly)
+#define SLAM_STAGE_MAX ((size_t)32 << 20)
+static char* stage_area(slam_ctx* ctx, size_t bytes) {
+    if (bytes > SLAM_STAGE_MAX) return nullptr;
+    if (bytes > ctx->h_stage_cap) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;  // nothing may still read the old area
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr;
+        ctx->h_stage_cap = 0;
+        size_t cap = (size_t)1 << 20;
+        while (cap < bytes) cap <<= 1;
+        if (hipHostMalloc((void**)&ctx->h_stage, cap, hipHostMallocDefault) != hipSuccess) { ctx->h_stage = nullptr; return nullptr; }
+        ctx->h_stage_cap = cap;
+    }
+    return ctx->h_stage;
+}
+
+// stage two (N,2) point arrays contiguously in ctx->pts; returns device pointers.  The host entry points that call
+// this synchronise before they return, so the staging area is free again at the next call.
 static int stage_points(slam_ctx* ctx, const double* p0, const double* p1, int64_t N, double** d0, double** d1) {
     const size_t bytes = (size_t)N * 2 * sizeof(double);
+    const size_t second = (bytes + 63) & ~(size_t)63;
     SLAM_TRY(slam_reserve(ctx, ctx->pts, 2 * bytes + 64));
     *d0 = (double*)ctx->pts.p;
-    *d1 = (double*)((char*)ctx->pts.p + ((bytes + 63) & ~(size_t)63));
+    *d1 = (double*)((char*)ctx->pts.p + second);
+    if (char* h = stage_area(ctx, second + bytes)) {
+        memcpy(h, p0, bytes);
+        memcpy(h + second, p1, bytes);
+        SLAM_HIP(ctx, hipMemcpyAsync(*d0, h, second + bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SLAM_OK;
+    }
     SLAM_HIP(ctx, hipMemcpyAsync(*d0, p0, bytes, hipMemcpyHostToDevice, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(*d1, p1, bytes, hipMemcpyHostToDevice, ctx->stream));
     return SLAM_OK;
@@ -547,6 +573,9 @@ extern "C" int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, 
     SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
     SLAM_REQUIRE(ctx, H >= 1, "H < 1");
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pts_bytes = (((size_t)N * 16 + 63) & ~(size_t)63) + (size_t)N * 16;
+    const size_t out_at = (pts_bytes + 255) & ~(size_t)255;
+    (void)stage_area(ctx, out_at + 256 + (size_t)N);  // sized once for the uploads and the downloads of this call
     double *d0, *d1;
     SLAM_TRY(stage_points(ctx, p0, p1, N, &d0, &d1));
     const int32_t* d_idx = nullptr;
@@ -562,12 +591,26 @@ extern "C" int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, 
     SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
     SLAM_TRY(ransac_enqueue(ctx, d0, d1, N, d_idx, sampler, seed, it0, H, threshold, (double*)ctx->record.p, d_mask,
                             (int32_t*)ctx->counts.p, (double*)ctx->errsums.p, (double*)ctx->F.p));
-    SLAM_HIP(ctx, hipMemcpyAsync(record, ctx->record.p, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (mask) SLAM_HIP(ctx, hipMemcpyAsync(mask, d_mask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    // record and mask come back through the pinned area (behind the staged points) and are handed over after the
+    // synchronisation of check_flags(); the optional per-hypothesis arrays go directly
+    char* h_out = stage_area(ctx, out_at + 256 + (size_t)N);
+    if (h_out) {
+        h_out += out_at;
+        SLAM_HIP(ctx, hipMemcpyAsync(h_out, ctx->record.p, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (mask) SLAM_HIP(ctx, hipMemcpyAsync(h_out + 256, d_mask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        SLAM_HIP(ctx, hipMemcpyAsync(record, ctx->record.p, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (mask) SLAM_HIP(ctx, hipMemcpyAsync(mask, d_mask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (counts) SLAM_HIP(ctx, hipMemcpyAsync(counts, ctx->counts.p, (size_t)H * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (errsums) SLAM_HIP(ctx, hipMemcpyAsync(errsums, ctx->errsums.p, (size_t)H * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (F_all) SLAM_HIP(ctx, hipMemcpyAsync(F_all, ctx->F.p, (size_t)H * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    return check_flags(ctx);
+    const int rc = check_flags(ctx);
+    if (h_out && rc != SLAM_EHIP) {
+        memcpy(record, h_out, SLAM_REC_LEN * sizeof(double));
+        if (mask) memcpy(mask, h_out + 256, (size_t)N);
+    }
+    return rc;
 }
 
 extern "C" int slam_ransac_f_adaptive(slam_ctx* ctx, const double* p0, const double* p1, int N, int sampler,

@@ -923,11 +923,17 @@ static int init_pair_on_device(slam_ctx* ctx, const double* r0, const double* r1
     SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(blocks), dim3(256), 0, (const double*)pw,
                          (const unsigned long long*)d_counts4, (const double*)ctx->X4.p, (int64_t)N, d_pose, d_winner,
                          (double*)ctx->X.p, (uint8_t*)ctx->mask.p, (const PairArgs*)nullptr));
-    if (X) SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (good) SLAM_HIP(ctx, hipMemcpyAsync(good, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    // points and flags come back through the pinned area (the uploads that may still sit in it were enqueued earlier
+    // on this stream, so they have been read by the time these copies write)
+    const size_t x_bytes = (size_t)N * 3 * sizeof(double);
+    char* h_out = (X || good) ? stage_area(ctx, x_bytes + (size_t)N) : nullptr;
+    if (X) SLAM_HIP(ctx, hipMemcpyAsync(h_out ? (void*)h_out : (void*)X, ctx->X.p, x_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (good) SLAM_HIP(ctx, hipMemcpyAsync(h_out ? (void*)(h_out + x_bytes) : (void*)good, ctx->mask.p, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
     double* hs = ctx->h_small;  // mirrors the device block `small` (1024 words)
     SLAM_HIP(ctx, hipMemcpyAsync(hs, small, 760 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_TRY(check_flags(ctx));
+    if (h_out && X) memcpy(X, h_out, x_bytes);
+    if (h_out && good) memcpy(good, h_out + x_bytes, (size_t)N);
     if (E) memcpy(E, hs + PW_E, 9 * sizeof(double));
     if (F) memcpy(F, hs + PW_F, 9 * sizeof(double));
     if (pose) memcpy(pose, hs + 710, 16 * sizeof(double));

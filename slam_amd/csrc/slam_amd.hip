@@ -1208,12 +1208,27 @@ extern "C" int slam_track_pose(slam_ctx* ctx, const double* previous_pose, const
     char* base = (char*)ctx->pts.p;
     double *da = (double*)base, *db = (double*)(base + b2), *dX3 = (double*)(base + 2 * b2);
     double *dpa = (double*)(base + 2 * b2 + b3), *dna = (double*)(base + 2 * b2 + b3 + bn);
-    SLAM_HIP(ctx, hipMemcpyAsync(da, prev_known, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(db, next_known, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(dX3, known_3d_points, (size_t)M * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (N > 0) {
-        SLAM_HIP(ctx, hipMemcpyAsync(dpa, prev_all, (size_t)N * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        SLAM_HIP(ctx, hipMemcpyAsync(dna, next_all, (size_t)N * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // the five arrays go up in one copy from the pinned area, laid out as on the device; the points come back through
+    // it as well (behind the uploads, in stream order)
+    const size_t up_bytes = 2 * b2 + b3 + 2 * bn, x_bytes = (size_t)N * 3 * sizeof(double);
+    char* h = stage_area(ctx, up_bytes + x_bytes);
+    if (h) {
+        memcpy(h, prev_known, (size_t)M * 2 * sizeof(double));
+        memcpy(h + b2, next_known, (size_t)M * 2 * sizeof(double));
+        memcpy(h + 2 * b2, known_3d_points, (size_t)M * 3 * sizeof(double));
+        if (N > 0) {
+            memcpy(h + 2 * b2 + b3, prev_all, (size_t)N * 2 * sizeof(double));
+            memcpy(h + 2 * b2 + b3 + bn, next_all, (size_t)N * 2 * sizeof(double));
+        }
+        SLAM_HIP(ctx, hipMemcpyAsync(base, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        SLAM_HIP(ctx, hipMemcpyAsync(da, prev_known, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(db, next_known, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(dX3, known_3d_points, (size_t)M * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (N > 0) {
+            SLAM_HIP(ctx, hipMemcpyAsync(dpa, prev_all, (size_t)N * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            SLAM_HIP(ctx, hipMemcpyAsync(dna, next_all, (size_t)N * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     double* d_pose = (double*)ctx->small.p + 710;
     SLAM_TRY(track_enqueue(ctx, previous_pose, da, db, dX3, M, dpa, dna, N, K, H, d_pose, (double*)ctx->X.p));
@@ -1221,13 +1236,14 @@ extern "C" int slam_track_pose(slam_ctx* ctx, const double* previous_pose, const
     double* hs = ctx->h_small;
     SLAM_HIP(ctx, hipMemcpyAsync(hs, d_pose, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(hs + 16, tw + TW_BEST, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (N > 0) SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (N > 0) SLAM_HIP(ctx, hipMemcpyAsync(h ? (void*)(h + up_bytes) : (void*)X, ctx->X.p, x_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (counts) SLAM_HIP(ctx, hipMemcpyAsync(counts, ctx->counts.p, (size_t)H * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (errs) SLAM_HIP(ctx, hipMemcpyAsync(errs, ctx->errsums.p, (size_t)H * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (poses)
         SLAM_HIP(ctx, hipMemcpy2DAsync(poses, 16 * sizeof(double), tw + TW_LEN + HP_POSE, HP_LEN * sizeof(double),
                                        16 * sizeof(double), (size_t)H, hipMemcpyDeviceToHost, ctx->stream));
     SLAM_TRY(check_flags(ctx));
+    if (h && N > 0) memcpy(X, h + up_bytes, x_bytes);
     memcpy(pose, hs, 16 * sizeof(double));
     if (best) memcpy(best, hs + 16, 3 * sizeof(double));
     return SLAM_OK;

@@ -565,6 +565,16 @@ static int stage_points(slam_ctx* ctx, const double* p0, const double* p1, int64
     return SLAM_OK;
 }
 
+// ctx->X (N x 3) to host memory through the pinned area, then synchronise; everything enqueued before is done after it
+static int download_points(slam_ctx* ctx, double* X, int64_t N) {
+    const size_t bytes = (size_t)N * 3 * sizeof(double);
+    char* h = stage_area(ctx, bytes);
+    SLAM_HIP(ctx, hipMemcpyAsync(h ? (void*)h : (void*)X, ctx->X.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h) memcpy(X, h, bytes);
+    return SLAM_OK;
+}
+
 extern "C" int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, int N, const int32_t* idx, int sampler,
                              uint64_t seed, int64_t it0, int H, double threshold, double* record, uint8_t* mask,
                              int32_t* counts, double* errsums, double* F_all) {
@@ -799,8 +809,7 @@ extern "C" int slam_triangulate(slam_ctx* ctx, const double* P0, const double* P
     SLAM_TRY(stage_points(ctx, p0, p1, N, &d0, &d1));
     SLAM_TRY(slam_reserve(ctx, ctx->X, (size_t)N * 3 * sizeof(double)));
     SLAM_TRY(slam_triangulate_dev(ctx, P0, P1, d0, d1, N, (double*)ctx->X.p));
-    SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SLAM_TRY(download_points(ctx, X, N));
     return SLAM_OK;
 }
 
@@ -861,11 +870,10 @@ extern "C" int slam_pose_from_E(slam_ctx* ctx, const double* E, const double* K,
     int32_t* d_winner = (int32_t*)(small + 730);
     SLAM_TRY(slam_pose_candidates_dev(ctx, E, K, d0, d1, N, d_counts4));
     SLAM_TRY(slam_pose_select_dev(ctx, d_counts4, N, d_pose, (double*)ctx->X.p, d_winner));
-    SLAM_HIP(ctx, hipMemcpyAsync(X, ctx->X.p, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_small + 32, d_counts4, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_small + 40, d_pose, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_small + 60, d_winner, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SLAM_TRY(download_points(ctx, X, N));
     memcpy(pose, ctx->h_small + 40, 16 * sizeof(double));
     const int64_t* c = (const int64_t*)(ctx->h_small + 32);
     if (counts4) for (int i = 0; i < 4; ++i) counts4[i] = (int32_t)c[i];

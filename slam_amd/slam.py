@@ -103,9 +103,11 @@ class Slam:
         camera_pose, points2d, points3d, good_points_mask = find_pose_and_triangulated_points(
             prev_frame, new_frame, self.intrinsic_camera_matrix, self.backend)
         self.log_camera_pose(camera_pose)
-        for idx in range(len(good_points_mask)):                 # every point, good or not: custom_slam.py:219-224
-            self.set_triangulated_point(current_frame_num, points2d[0][idx], points3d[idx])
-            self.set_triangulated_point(current_frame_num + 1, points2d[1][idx], points3d[idx])
+        # every point, good or not (custom_slam.py:219-224), registered for both frames; built in bulk: the keys are
+        # the same (x, y) tuples set_triangulated_point makes, a later duplicate of a 2D point wins as it does there
+        for frame_num, pts in ((current_frame_num, points2d[0]), (current_frame_num + 1, points2d[1])):
+            self.triangulated_point_lookup.setdefault(frame_num, {}).update(
+                zip(map(tuple, np.asarray(pts).tolist()), points3d[:len(good_points_mask)]))
         self.add_triangulated_points(points3d[good_points_mask])
         self.add_camera_pose(camera_pose)
         self.latest_image_2d_points = points2d[1]
@@ -118,16 +120,13 @@ class Slam:
         current_frame_num = self.current_frame_num()
         latest_camera_pose = self.get_latest_camera_pose()
         prev_image_points, new_image_points = self.backend.matches(prev_frame, new_frame)
-        prev_known, new_known, known_3d = [], [], []
-        for prev_point, new_point in zip(prev_image_points, new_image_points):
-            point_3d = self.get_triangulated_point(current_frame_num, prev_point)
-            if point_3d is not None:
-                prev_known.append(prev_point)
-                new_known.append(new_point)
-                known_3d.append(point_3d)
-        pose, points = self.backend.track(latest_camera_pose, np.array(prev_known), np.array(new_known),
-                                          np.array(known_3d), prev_image_points, new_image_points,
-                                          self.intrinsic_camera_matrix)
+        # the matches whose previous point has a 3D position (custom_slam.py:239-245), looked up in bulk
+        known_here = self.triangulated_point_lookup.get(current_frame_num, {})
+        found = [known_here.get(key) for key in map(tuple, np.asarray(prev_image_points).tolist())]
+        keep = [i for i, point_3d in enumerate(found) if point_3d is not None]
+        pose, points = self.backend.track(latest_camera_pose, np.asarray(prev_image_points)[keep],
+                                          np.asarray(new_image_points)[keep], np.array([found[i] for i in keep]),
+                                          prev_image_points, new_image_points, self.intrinsic_camera_matrix)
         self.log_camera_pose(pose)
         self.add_camera_pose(pose)
         return pose

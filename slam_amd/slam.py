@@ -39,6 +39,11 @@ class GpuBackend:
         r = pipeline.initialise_pair(img0_points, img1_points, K, self.iterations, ctx=self.ctx)
         return r["pose"], r["X"], r["mask"]
 
+    def pair_from_frames(self, f0, f1, K):
+        from . import pipeline
+        r = pipeline.frame_pair(f0.keypoints, f0.descriptors, f1.keypoints, f1.descriptors, K, self.iterations, ctx=self.ctx)
+        return r["pose"], [r["matched0"], r["matched1"]], r["X"], r["mask"]
+
     def track(self, pose, prev_known, next_known, X_known, prev_all, next_all, K):
         from . import triangulation
         return triangulation.triangulate_pose_from_points_with_ransac(pose, prev_known, next_known, X_known, prev_all,
@@ -47,6 +52,8 @@ class GpuBackend:
 
 def find_pose_and_triangulated_points(frame0, frame1, intrinsic_camera_matrix, backend):
     """reference: custom_slam.py:105-115 (matching, F by RANSAC, E, pose and points, z > 0 flags)"""
+    if hasattr(backend, "pair_from_frames"):  # both stages in one library call, the matches never leave the device
+        return backend.pair_from_frames(frame0, frame1, intrinsic_camera_matrix)
     img0_points, img1_points = backend.matches(frame0, frame1)
     pose, X, good = backend.initialise(img0_points, img1_points, intrinsic_camera_matrix)
     return pose, [img0_points, img1_points], X, good

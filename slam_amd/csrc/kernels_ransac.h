@@ -620,7 +620,8 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
 // K3: selection   (reference: src/epipolar.py:78-81 applied in iteration order)
 //   a later hypothesis replaces the incumbent iff it has more inliers, or as many and a strictly smaller errsum;
 //   hence the winner is the lexicographic best of (count desc, errsum asc, index asc).
-// Single workgroup; also emits the winner's record and inlier mask.
+// Every workgroup of the grid finds the winner for itself; workgroup 0 emits its record, all of them share the
+// winner's inlier mask.
 // ------------------------------------------------------------------------------------------------
 struct Best {
     int count;

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import c_oracle as co
 from oracle import slam_oracle as so
-from slam_amd import _lib, epipolar, logger, synth
+from slam_amd import _lib, epipolar, logger, pipeline, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -86,3 +86,26 @@ def test_adaptive_runs_to_the_limit_when_nothing_fits(ctx):
     assert r["iterations_run"] == 3000
     fixed = epipolar.ransac_detailed(p0, p1, 3000, ctx=ctx)
     assert np.array_equal(r["record"], fixed["record"])
+
+
+def test_stream_priority_setting_is_checked(monkeypatch):
+    """SLAM_AMD_STREAM_PRIORITY selects the priority level of a context's streams: high (default), normal, low; anything
+    else makes slam_create fail with a message, and every valid level gives a working context."""
+    import ctypes as C
+    lib = _lib.load()
+    d = synth.make_pair(300, 0.3, seed=5)
+    n0, _ = pipeline.normalize_points(d["pts0"])
+    n1, _ = pipeline.normalize_points(d["pts1"])
+    want = epipolar.ransac_detailed(n0, n1, 50)
+    for level in ("normal", "low", "high"):
+        monkeypatch.setenv("SLAM_AMD_STREAM_PRIORITY", level)
+        ctx = _lib.Context(0)
+        try:
+            got = epipolar.ransac_detailed(n0, n1, 50, ctx=ctx)
+            assert got["best_index"] == want["best_index"] and got["best_count"] == want["best_count"], level
+        finally:
+            ctx.close()
+    monkeypatch.setenv("SLAM_AMD_STREAM_PRIORITY", "urgent")
+    handle = C.c_void_p()
+    assert lib.slam_create(0, C.byref(handle)) < 0
+    assert b"SLAM_AMD_STREAM_PRIORITY" in lib.slam_last_error(None)

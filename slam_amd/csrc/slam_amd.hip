@@ -1324,23 +1324,43 @@ static int match_host(slam_ctx* ctx, const uint8_t* des0, const double* pts0, in
     int32_t* d_index = (int32_t*)take(b_i);
     int32_t* d_distance = (int32_t*)take(b_i);
     int32_t* d_n = (int32_t*)take(256);
-    SLAM_HIP(ctx, hipMemcpyAsync(d_d0, des0, (size_t)n0 * 32, hipMemcpyHostToDevice, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(d_d1, des1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (gather) {
-        SLAM_HIP(ctx, hipMemcpyAsync(d_p0, pts0, (size_t)n0 * 16, hipMemcpyHostToDevice, ctx->stream));
-        SLAM_HIP(ctx, hipMemcpyAsync(d_p1, pts1, (size_t)n1 * 16, hipMemcpyHostToDevice, ctx->stream));
+    // descriptors and keypoints go up in one copy from the pinned area (laid out as on the device: d0 | d1 | p0 | p1);
+    // the matched points come back through it at full capacity together with their count: one synchronisation
+    const size_t up_bytes = b_d0 + b_d1 + b_p0 + b_p1;
+    char* h = stage_area(ctx, up_bytes + 2 * b_m);
+    if (h) {
+        memcpy(h, des0, (size_t)n0 * 32);
+        memcpy(h + b_d0, des1, (size_t)n1 * 32);
+        if (gather) {
+            memcpy(h + b_d0 + b_d1, pts0, (size_t)n0 * 16);
+            memcpy(h + b_d0 + b_d1 + b_p0, pts1, (size_t)n1 * 16);
+        }
+        SLAM_HIP(ctx, hipMemcpyAsync(d_d0, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        SLAM_HIP(ctx, hipMemcpyAsync(d_d0, des0, (size_t)n0 * 32, hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(d_d1, des1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
+        if (gather) {
+            SLAM_HIP(ctx, hipMemcpyAsync(d_p0, pts0, (size_t)n0 * 16, hipMemcpyHostToDevice, ctx->stream));
+            SLAM_HIP(ctx, hipMemcpyAsync(d_p1, pts1, (size_t)n1 * 16, hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     SLAM_TRY(match_enqueue(ctx, d_d0, d_p0, n0, d_d1, d_p1, n1, slices, d_part, d_m0, d_m1, d_n, d_index, d_distance));
     int32_t* h_n = (int32_t*)(ctx->h_small + 128);
     SLAM_HIP(ctx, hipMemcpyAsync(h_n, d_n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (index) SLAM_HIP(ctx, hipMemcpyAsync(index, d_index, (size_t)n0 * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (distance) SLAM_HIP(ctx, hipMemcpyAsync(distance, d_distance, (size_t)n0 * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (gather && h) SLAM_HIP(ctx, hipMemcpyAsync(h + up_bytes, d_m0, 2 * b_m, hipMemcpyDeviceToHost, ctx->stream));  // m0 | m1
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_matched) *n_matched = *h_n;
     if (gather && *h_n > 0) {
-        SLAM_HIP(ctx, hipMemcpyAsync(matched0, d_m0, (size_t)*h_n * 16, hipMemcpyDeviceToHost, ctx->stream));
-        SLAM_HIP(ctx, hipMemcpyAsync(matched1, d_m1, (size_t)*h_n * 16, hipMemcpyDeviceToHost, ctx->stream));
-        SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h) {
+            memcpy(matched0, h + up_bytes, (size_t)*h_n * 16);
+            memcpy(matched1, h + up_bytes + b_m, (size_t)*h_n * 16);
+        } else {
+            SLAM_HIP(ctx, hipMemcpyAsync(matched0, d_m0, (size_t)*h_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+            SLAM_HIP(ctx, hipMemcpyAsync(matched1, d_m1, (size_t)*h_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+            SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     return SLAM_OK;
 }

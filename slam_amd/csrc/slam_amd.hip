@@ -1415,20 +1415,38 @@ extern "C" int slam_frame_pair(slam_ctx* ctx, const uint8_t* des0, const double*
     double* d_m0 = (double*)take(b_m);
     double* d_m1 = (double*)take(b_m);
     int32_t* d_n = (int32_t*)take(256);
-    SLAM_HIP(ctx, hipMemcpyAsync(d_d0, des0, (size_t)n0 * 32, hipMemcpyHostToDevice, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(d_d1, des1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(d_p0, pts0, (size_t)n0 * 16, hipMemcpyHostToDevice, ctx->stream));
-    SLAM_HIP(ctx, hipMemcpyAsync(d_p1, pts1, (size_t)n1 * 16, hipMemcpyHostToDevice, ctx->stream));
+    // one upload from the pinned area (d0 | d1 | p0 | p1 as on the device); the matched points come back through it at
+    // full capacity together with their count
+    const size_t up_bytes = b_d0 + b_d1 + b_p0 + b_p1;
+    char* h = stage_area(ctx, up_bytes + 2 * b_m);
+    if (h) {
+        memcpy(h, des0, (size_t)n0 * 32);
+        memcpy(h + b_d0, des1, (size_t)n1 * 32);
+        memcpy(h + b_d0 + b_d1, pts0, (size_t)n0 * 16);
+        memcpy(h + b_d0 + b_d1 + b_p0, pts1, (size_t)n1 * 16);
+        SLAM_HIP(ctx, hipMemcpyAsync(d_d0, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        SLAM_HIP(ctx, hipMemcpyAsync(d_d0, des0, (size_t)n0 * 32, hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(d_d1, des1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(d_p0, pts0, (size_t)n0 * 16, hipMemcpyHostToDevice, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(d_p1, pts1, (size_t)n1 * 16, hipMemcpyHostToDevice, ctx->stream));
+    }
     SLAM_TRY(match_enqueue(ctx, d_d0, d_p0, n0, d_d1, d_p1, n1, slices, d_part, d_m0, d_m1, d_n, nullptr, nullptr));
     // the number of matches sizes every later launch: the one value that has to come back in the middle
     int32_t* h_n = (int32_t*)(ctx->h_small + 128);
     SLAM_HIP(ctx, hipMemcpyAsync(h_n, d_n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (h) SLAM_HIP(ctx, hipMemcpyAsync(h + up_bytes, d_m0, 2 * b_m, hipMemcpyDeviceToHost, ctx->stream));  // m0 | m1
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int M = *h_n;
     *n_matched = M;
     if (M > 0) {
-        SLAM_HIP(ctx, hipMemcpyAsync(matched0, d_m0, (size_t)M * 16, hipMemcpyDeviceToHost, ctx->stream));
-        SLAM_HIP(ctx, hipMemcpyAsync(matched1, d_m1, (size_t)M * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (h) {
+            memcpy(matched0, h + up_bytes, (size_t)M * 16);
+            memcpy(matched1, h + up_bytes + b_m, (size_t)M * 16);
+        } else {
+            SLAM_HIP(ctx, hipMemcpyAsync(matched0, d_m0, (size_t)M * 16, hipMemcpyDeviceToHost, ctx->stream));
+            SLAM_HIP(ctx, hipMemcpyAsync(matched1, d_m1, (size_t)M * 16, hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
     if (M < 8) {  // the reference asserts here (src/epipolar.py:60)
         SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));

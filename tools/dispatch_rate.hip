@@ -44,6 +44,26 @@ int main() {
                sh.grid, sh.block, sh.iters, sh.iters * 9.0 / 2350.0, dt / (launches * T) * 1e6);
         for (auto& s : st) hipStreamDestroy(s);
     }
+    // tiny grids (8 workgroups of one wave) with a long body: whatever limits their overlap is not a CU resource
+    for (int T : {1, 2, 4, 8}) {
+        std::vector<hipStream_t> st(T);
+        for (auto& s : st) hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi);
+        std::atomic<int> go{0};
+        std::vector<std::thread> th;
+        const int n = 2000;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                while (!go.load()) {}
+                for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_busy, dim3(8), dim3(64), 0, st[t], d, 4000);
+                hipStreamSynchronize(st[t]);
+            });
+        const auto t0 = std::chrono::steady_clock::now();
+        go.store(1);
+        for (auto& x : th) x.join();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("8 x 64-thread grids with a long body, %d thread(s) with a stream each: %.2f us per launch\n", T, dt / (n * T) * 1e6);
+        for (auto& s : st) hipStreamDestroy(s);
+    }
     // the same busy kernel on 6 streams from 3 threads: all at one priority, or two per priority level
     for (int mixed : {0, 1}) {
         const int T = 3, L = 2;

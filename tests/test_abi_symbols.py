@@ -56,3 +56,20 @@ def test_create_fails_loudly_without_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(_lib.SlamError):
         _lib.Context(0)
+
+
+def test_binding_constants_equal_the_header():
+    """Every numeric #define / enum value of the header that the Python binding repeats has the same value there."""
+    text = open(os.path.join(REPO, "include", "slam_amd.h")).read()
+    values = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(SLAM_[A-Z0-9_]+)\s+(-?(?:0x[0-9A-Fa-f]+|\d+))\b", text)}
+    values.update({m.group(1): int(m.group(2)) for m in re.finditer(r"\b(SLAM_E[A-Z]+)\s*=\s*(-?\d+)", text)})
+    pairs = {"SLAM_SAMPLER_CPYTHON": "SAMPLER_CPYTHON", "SLAM_SAMPLER_COUNTER": "SAMPLER_COUNTER", "SLAM_REC_COUNT": "REC_COUNT",
+             "SLAM_REC_ERRSUM": "REC_ERRSUM", "SLAM_REC_INDEX": "REC_INDEX", "SLAM_REC_F": "REC_F", "SLAM_REC_LEN": "REC_LEN",
+             "SLAM_SCORE_ALGEBRAIC": "SCORE_ALGEBRAIC", "SLAM_SCORE_SAMPSON": "SCORE_SAMPSON", "SLAM_K_SOLVE": "K_SOLVE",
+             "SLAM_K_SCORE": "K_SCORE", "SLAM_K_SELECT": "K_SELECT", "SLAM_K_TRIANGULATE": "K_TRIANGULATE"}
+    checked = 0
+    for c_name, py_name in pairs.items():
+        if c_name in values and hasattr(_lib, py_name):
+            assert values[c_name] == getattr(_lib, py_name), c_name
+            checked += 1
+    assert checked >= 10

@@ -380,6 +380,14 @@ def main():
         t0 = time.perf_counter()
         res = pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)
         bdt = stop_clock() - t0
+        # the same batch handed over already packed (one array per image side and the row offsets)
+        pk0, pk1 = np.concatenate([a_ for a_, _ in plist]), np.concatenate([b_ for _, b_ in plist])
+        pko = np.arange(len(plist) + 1, dtype=np.int64) * NB
+        pipeline.initialise_pairs_packed(pk0, pk1, pko, Kb, iterations=IB, ctx=ctx)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            packed = pipeline.initialise_pairs_packed(pk0, pk1, pko, Kb, iterations=IB, ctx=ctx)
+        pdt = (time.perf_counter() - t0) / 5
         t0 = time.perf_counter()
         one = [pipeline.initialise_pair(a_, b_, Kb, iterations=IB, ctx=ctx) for a_, b_ in plist[:10]]
         sdt = (time.perf_counter() - t0) / 10
@@ -391,6 +399,8 @@ def main():
                                                 f"split over {world} GPU(s); whole initialisation per pair (normalise, RANSAC, "
                                                 "F->E, 4-candidate triangulation, selection), host buffers in and out, one call per rank",
                                     "scaling": "strong", "ms_per_batch": bdt * 1e3, "pairs_per_sec": NP_ / bdt,
+                                    "ms_per_batch_packed_input_this_rank": pdt * 1e3,
+                                    "packed_equals_list": bool(np.array_equal(packed["X"], np.concatenate([r_["X"] for r_ in res]))),
                                     "hypotheses_per_sec": NP_ * IB / bdt, "us_per_pair_single_calls": sdt * 1e6,
                                     "same_as_single_calls": bool(all(np.array_equal(x["X"], y["X"]) for x, y in zip(res, one))),
                                     "mean_inliers": float(np.mean([r["record"][_lib.REC_COUNT] for r in res]))}

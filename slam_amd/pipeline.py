@@ -83,6 +83,28 @@ def initialise_pairs(pairs, intrinsic_camera_matrix, iterations=1000, ctx=None):
     return out
 
 
+def initialise_pairs_packed(pts0, pts1, offsets, intrinsic_camera_matrix, iterations=1000, ctx=None):
+    """initialise_pairs for a caller that already holds its batch packed: pts0, pts1 (total, 2) float64 with pair p in
+    rows offsets[p]:offsets[p+1].  Returns arrays instead of a list of dicts: F, E (P,3,3), pose (P,4,4), X (total,3),
+    mask (total,) bool, record (P,12), counts (P,4), winner (P,).  Same numbers as initialise_pairs."""
+    p0, p1, K = f64(np.asarray(pts0)), f64(np.asarray(pts1)), f64(intrinsic_camera_matrix)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    P = len(offsets) - 1
+    assert P >= 1 and p0.shape == p1.shape and p0.ndim == 2 and p0.shape[1] == 2
+    assert offsets[0] == 0 and offsets[-1] == len(p0) and np.all(np.diff(offsets) >= 8)
+    total = len(p0)
+    F, E, pose = np.empty((P, 3, 3)), np.empty((P, 3, 3)), np.empty((P, 4, 4))
+    X = np.empty((total, 3))
+    good = np.empty(total, dtype=np.uint8)
+    record = np.empty((P, REC_LEN))
+    counts4 = np.empty((P, 4), dtype=np.int32)
+    winner = np.empty(P, dtype=np.int32)
+    ctx = ctx or _lib.default_context()
+    ctx.check(ctx.lib.slam_init_pairs(ctx.handle, ptr(p0), ptr(p1), ptr(offsets), P, ptr(K), int(iterations), ptr(F), ptr(E),
+                                      ptr(pose), ptr(X), ptr(good), ptr(record), ptr(counts4), ptr(winner)))
+    return dict(F=F, E=E, pose=pose, X=X, mask=good.view(np.bool_), record=record, counts=counts4, winner=winner)
+
+
 def frame_pair(img0_pts, img0_des, img1_pts, img1_des, intrinsic_camera_matrix, iterations=1000, ctx=None):
     """Keypoints and descriptors of two images -> matches (2-NN, ratio test) -> whole two-view initialisation, in one
     library call; the matches stay on the device between the two stages   (reference: custom_slam.py:56-82 after the

@@ -149,6 +149,14 @@ def test_random_pairs_whole_initialisation_against_c_restatement(seed):
     K = synth.KITTI_K
     singles = [pipeline.initialise_pair(p0, p1, K, 200, ctx=ctx) for p0, p1 in pairs]
     batch = pipeline.initialise_pairs(pairs, K, 200, ctx=ctx)
+    # the packed form of the same call returns the same numbers as arrays
+    offsets = np.concatenate([[0], np.cumsum([len(p0) for p0, _ in pairs])])
+    packed = pipeline.initialise_pairs_packed(np.concatenate([p0 for p0, _ in pairs]), np.concatenate([p1 for _, p1 in pairs]),
+                                              offsets, K, 200, ctx=ctx)
+    assert np.array_equal(packed["X"], np.concatenate([b["X"] for b in batch]), equal_nan=True)
+    assert np.array_equal(packed["mask"], np.concatenate([b["mask"] for b in batch]))
+    assert np.array_equal(packed["pose"], np.stack([b["pose"] for b in batch]), equal_nan=True)
+    assert np.array_equal(packed["winner"], [b["winner"] for b in batch])
     checked = 0
     for case, (r, b, (pose, X, good)) in enumerate(zip(singles, batch, wants)):
         where = f"seed {seed} case {case}: N={len(pairs[case][0])}"

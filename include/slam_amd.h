@@ -76,6 +76,11 @@ int slam_set_concurrency(slam_ctx* ctx, int lanes);
 int slam_set_scoring(slam_ctx* ctx, int mode);
 /* waits for everything the context has queued, on every internal stream */
 int slam_synchronize(slam_ctx* ctx);
+/* Page-locked host memory for callers that want the host entry points to transfer at the full PCIe rate (the library
+ * copies arrays in pageable memory through a staging area; arrays in page-locked memory go directly when they are
+ * larger than that area).  No counterpart in the reference. */
+int slam_host_alloc(slam_ctx* ctx, uint64_t bytes, void** out);
+int slam_host_free(slam_ctx* ctx, void* p); /* ctx may be NULL: the memory may outlive its context */
 
 /* ---- sampler: src/epipolar.py:62,69-71 ---------------------------------------------------------- */
 /* number of hypotheses the reference runs: min(iterations, C(N, 8))   (src/epipolar.py:69) */

@@ -32,6 +32,8 @@ SIGNATURES = {
     "slam_set_concurrency": (_int, [_vp, _int]),
     "slam_set_scoring": (_int, [_vp, _int]),
     "slam_synchronize": (_int, [_vp]),
+    "slam_host_alloc": (_int, [_vp, _u64, C.POINTER(C.c_void_p)]),
+    "slam_host_free": (_int, [_vp, _vp]),
     "slam_num_hypotheses": (_i64, [_i64, _i64]),
     "slam_sample_indices": (_int, [_vp, _int, _u64, _i64, _int, _int, _int, _vp]),
     "slam_eightpoint": (_int, [_vp, _vp, _vp, _int, _vp]),
@@ -137,6 +139,21 @@ class Context:
                 raise AssertionError(msg)
             raise SlamError(f"libslam_amd error {rc}: {msg}")
         return rc
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """An uninitialised numpy array in page-locked host memory (slam_host_alloc): transfers from and to it run at
+        the full PCIe rate.  The memory is released when the array and all its views are gone."""
+        import weakref
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = max(1, count * dtype.itemsize)
+        p = C.c_void_p()
+        self.check(self.lib.slam_host_alloc(self.handle, nbytes, C.byref(p)))
+        buf = (C.c_char * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+        lib, addr = self.lib, p.value
+        weakref.finalize(buf, lambda: lib.slam_host_free(None, addr))
+        return arr
 
     def close(self):
         if getattr(self, "handle", None):

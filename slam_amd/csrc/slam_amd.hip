@@ -145,6 +145,26 @@ extern "C" int slam_set_concurrency(slam_ctx* ctx, int lanes) {
     return SLAM_OK;
 }
 
+extern "C" int slam_host_alloc(slam_ctx* ctx, uint64_t bytes, void** out) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, out != nullptr && bytes > 0, "out is NULL or bytes is 0");
+    *out = nullptr;
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    if (hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        *out = nullptr;
+        snprintf(ctx->err, sizeof ctx->err, "page-locked allocation of %llu bytes failed", (unsigned long long)bytes);
+        return SLAM_ENOMEM;
+    }
+    return SLAM_OK;
+}
+
+extern "C" int slam_host_free(slam_ctx* ctx, void* p) {  // ctx may be NULL (memory may outlive the context it came from)
+    if (!p) return SLAM_OK;
+    if (!ctx) return hipHostFree(p) == hipSuccess ? SLAM_OK : SLAM_EHIP;
+    SLAM_HIP(ctx, hipHostFree(p));
+    return SLAM_OK;
+}
+
 extern "C" int slam_set_scoring(slam_ctx* ctx, int mode) {
     if (!ctx) return SLAM_EINVAL;
     SLAM_REQUIRE(ctx, mode == SLAM_SCORE_ALGEBRAIC || mode == SLAM_SCORE_SAMPSON, "unknown scoring mode");

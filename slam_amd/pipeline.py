@@ -83,22 +83,30 @@ def initialise_pairs(pairs, intrinsic_camera_matrix, iterations=1000, ctx=None):
     return out
 
 
-def initialise_pairs_packed(pts0, pts1, offsets, intrinsic_camera_matrix, iterations=1000, ctx=None):
+def initialise_pairs_packed(pts0, pts1, offsets, intrinsic_camera_matrix, iterations=1000, ctx=None, out=None):
     """initialise_pairs for a caller that already holds its batch packed: pts0, pts1 (total, 2) float64 with pair p in
     rows offsets[p]:offsets[p+1].  Returns arrays instead of a list of dicts: F, E (P,3,3), pose (P,4,4), X (total,3),
-    mask (total,) bool, record (P,12), counts (P,4), winner (P,).  Same numbers as initialise_pairs."""
+    mask (total,) bool, record (P,12), counts (P,4), winner (P,).  Same numbers as initialise_pairs.
+    out: a dict returned by an earlier call of the same shape (or with X and mask from Context.pinned_empty), whose
+    arrays are written again instead of allocating new ones."""
     p0, p1, K = f64(np.asarray(pts0)), f64(np.asarray(pts1)), f64(intrinsic_camera_matrix)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     P = len(offsets) - 1
     assert P >= 1 and p0.shape == p1.shape and p0.ndim == 2 and p0.shape[1] == 2
     assert offsets[0] == 0 and offsets[-1] == len(p0) and np.all(np.diff(offsets) >= 8)
     total = len(p0)
-    F, E, pose = np.empty((P, 3, 3)), np.empty((P, 3, 3)), np.empty((P, 4, 4))
-    X = np.empty((total, 3))
-    good = np.empty(total, dtype=np.uint8)
-    record = np.empty((P, REC_LEN))
-    counts4 = np.empty((P, 4), dtype=np.int32)
-    winner = np.empty(P, dtype=np.int32)
+    if out is not None:
+        F, E, pose, X, record, counts4, winner = (out[k] for k in ("F", "E", "pose", "X", "record", "counts", "winner"))
+        good = out["mask"].view(np.uint8)
+        assert X.shape == (total, 3) and good.shape == (total,) and F.shape == (P, 3, 3) and pose.shape == (P, 4, 4)
+        assert all(a.flags.c_contiguous for a in (F, E, pose, X, good, record, counts4, winner))
+    else:
+        F, E, pose = np.empty((P, 3, 3)), np.empty((P, 3, 3)), np.empty((P, 4, 4))
+        X = np.empty((total, 3))
+        good = np.empty(total, dtype=np.uint8)
+        record = np.empty((P, REC_LEN))
+        counts4 = np.empty((P, 4), dtype=np.int32)
+        winner = np.empty(P, dtype=np.int32)
     ctx = ctx or _lib.default_context()
     ctx.check(ctx.lib.slam_init_pairs(ctx.handle, ptr(p0), ptr(p1), ptr(offsets), P, ptr(K), int(iterations), ptr(F), ptr(E),
                                       ptr(pose), ptr(X), ptr(good), ptr(record), ptr(counts4), ptr(winner)))

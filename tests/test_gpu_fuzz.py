@@ -157,6 +157,15 @@ def test_random_pairs_whole_initialisation_against_c_restatement(seed):
     assert np.array_equal(packed["mask"], np.concatenate([b["mask"] for b in batch]))
     assert np.array_equal(packed["pose"], np.stack([b["pose"] for b in batch]), equal_nan=True)
     assert np.array_equal(packed["winner"], [b["winner"] for b in batch])
+    # and again with the inputs and the large outputs in page-locked memory, written into the arrays handed in
+    p_in0, p_in1 = ctx.pinned_empty((int(offsets[-1]), 2)), ctx.pinned_empty((int(offsets[-1]), 2))
+    p_in0[:], p_in1[:] = np.concatenate([p0 for p0, _ in pairs]), np.concatenate([p1 for _, p1 in pairs])
+    out = dict(packed)
+    out["X"], out["mask"] = ctx.pinned_empty(packed["X"].shape), ctx.pinned_empty(packed["mask"].shape, np.bool_)
+    again = pipeline.initialise_pairs_packed(p_in0, p_in1, offsets, K, 200, ctx=ctx, out=out)
+    assert again["X"] is out["X"]
+    assert np.array_equal(again["X"], np.concatenate([b["X"] for b in batch]), equal_nan=True)
+    assert np.array_equal(again["mask"], np.concatenate([b["mask"] for b in batch]))
     checked = 0
     for case, (r, b, (pose, X, good)) in enumerate(zip(singles, batch, wants)):
         where = f"seed {seed} case {case}: N={len(pairs[case][0])}"

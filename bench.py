@@ -41,7 +41,6 @@ PEAK_HBM = 8000.0               # GB/s
 # part the two peaks coincide
 BOUND_DETAIL = "FP64 vector ALU issue (no MFMA instructions); MI355X's dense FP64 MFMA peak is the same 78.6 TFLOP/s"
 TRI_FLOP_PER_CAND = 700.0       # executed per (point, candidate): D build/scaling 80, warm start 550, Jacobi check 70
-TRI_FLOP_COLD_SVD = 2200.0        # a cold 4x4 Jacobi SVD per triangulation would cost this much; reported alongside
 TRI_BYTES_PER_POINT = 88.0      # algorithmic: 2 x 32 B in (count pass + write pass) + 24 B out
 
 
@@ -52,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--tri-points", type=int, default=1 << 24)
     ap.add_argument("--lanes", type=int, default=4, help="independent steps the library may keep in flight (1..4)")
+    ap.add_argument("--bursts", type=int, default=50, help="timed bursts of --steps steps each; the median burst is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true")
     args = ap.parse_args()
@@ -99,9 +99,16 @@ def main():
             torch.cuda.synchronize()
 
     def stop_clock():
-        """Closing bracket: barrier + synchronise, then read the clock."""
-        barrier()
-        return time.perf_counter()
+        """Closing bracket: synchronise the device (every stream, the library's internal ones included), meet the
+        other ranks, read the clock.  The library's own end-of-queue check (slam_synchronize, which also fetches the
+        kernels' error flags) runs after the clock has been read: it is bookkeeping, not part of a step."""
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t = time.perf_counter()
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        return t
 
     # ---- inputs: one frame pair per rank, normalised as the reference's caller does, resident in HBM
     pair = synth.make_pair(N_MATCHES, OUTLIERS, seed=2 + rank)
@@ -145,32 +152,40 @@ def main():
         ctx.check(lib.slam_synchronize(ctx.handle))
     for _ in range(args.warmup):
         step()
-    # the timed loop issues exactly K steps, one library call each, cycling over the LANES prepared calls; the list is
-    # laid out beforehand so that the loop itself is nothing but the calls
-    timed = [jobs[(calls[0] + i) % LANES] for i in range(args.steps)]
-    failed = 0
-    barrier()
-    t0 = time.perf_counter()
-    for job in timed:
-        failed |= run(job)
-    dt = stop_clock() - t0
-    calls[0] += args.steps
-    if failed:
-        ctx.check(-2)  # raises with the library's message for the last failure
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # The timed region: K steps, one library call each, cycling over the LANES prepared calls, bracketed by the
+    # barrier + synchronise pair on both sides.  K steps of a few microseconds are mostly pipeline fill and drain, so
+    # the region is repeated: BURSTS bursts of K steps, each bracketed in the same way, and ms_per_step is the MEDIAN
+    # burst divided by K (min and max are reported too).  A run with K=20 and one with K=2000 then describe the same
+    # steady state, the short one with a little more fill per burst.
+    BURSTS = max(args.bursts, 1)
+
+    def timed_bursts(jobs_for_burst):
+        times, failed = [], 0
+        for _ in range(BURSTS):
+            barrier()
+            t0 = time.perf_counter()
+            for job in jobs_for_burst:
+                failed |= run(job)
+            times.append(stop_clock() - t0)
+        if failed:
+            ctx.check(-2)  # raises with the library's message for the last failure
+        t = np.array(times)
+        if use_dist:       # a burst lasts as long as its slowest rank
+            tt = torch.from_numpy(t).to(dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = tt.cpu().numpy()
+        return t
+
+    timed = [jobs[i % LANES] for i in range(args.steps)]
+    bt = timed_bursts(timed)
+    dt = float(np.median(bt))
     rec = d_rec.cpu().numpy()
     assert all(torch.equal(r, recs[0]) for r in recs), "lanes disagree"
     value = world * N_HYP * args.steps / dt
     # the same K steps strictly one after the other (one stream): the latency of a single call
     ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    dt_serial = stop_clock() - t0
+    bs = timed_bursts([jobs[0]] * args.steps)
+    dt_serial = float(np.median(bs))
 
     # ---- roofline of the scoring kernel: per-launch durations from HIP events on the library's stream
     ctx.check(lib.slam_profile_enable(ctx.handle, 1))
@@ -209,7 +224,11 @@ def main():
                       "n_matches": N_MATCHES, "hypotheses": N_HYP, "outlier_fraction": OUTLIERS,
                       "sharding": "independent frame pairs per GPU, no collective"},
            "residual_evals_per_sec": value * N_MATCHES,
+           "bursts": BURSTS, "ms_per_step_min": float(bt.min()) / args.steps * 1e3,
+           "ms_per_step_max": float(bt.max()) / args.steps * 1e3,
            "steps_in_flight": LANES, "ms_per_step_one_stream": dt_serial / args.steps * 1e3,
+           "ms_per_step_one_stream_min": float(bs.min()) / args.steps * 1e3,
+           "ms_per_step_one_stream_max": float(bs.max()) / args.steps * 1e3,
            "winner": {"index": int(rec[_lib.REC_INDEX]), "inliers": int(rec[_lib.REC_COUNT])},
            "roofline": roofline}
 
@@ -362,7 +381,6 @@ def main():
                       "roofline": {"kernel": "k_triangulate4", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": tf,
                                    "peak": PEAK_FP64_VALU, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU,
                                    "avg_launch_ms": tri_ms, "flop_per_candidate": TRI_FLOP_PER_CAND,
-                                   "frac_at_cold_svd_convention_2200_flop": tf * TRI_FLOP_COLD_SVD / TRI_FLOP_PER_CAND / PEAK_FP64_VALU,
                                    "hbm_GBps_algorithmic": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9,
                                    "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM}}
         del p0, p1, d_X

@@ -74,7 +74,9 @@ int slam_set_concurrency(slam_ctx* ctx, int lanes);
 #define SLAM_SCORE_ALGEBRAIC 0
 #define SLAM_SCORE_SAMPSON 1
 int slam_set_scoring(slam_ctx* ctx, int mode);
-/* waits for everything the context has queued, on every internal stream */
+/* Waits for everything the context has queued, on every internal stream.  Returns SLAM_ESAMPLER when a sampler of an
+ * asynchronous (_dev / job) call queued since the last check ran out of pre-generated words: those calls cannot
+ * report it when they return. */
 int slam_synchronize(slam_ctx* ctx);
 /* Page-locked host memory for callers that want the host entry points to transfer at the full PCIe rate (the library
  * copies arrays in pageable memory through a staging area; arrays in page-locked memory go directly when they are
@@ -167,8 +169,11 @@ int slam_init_pair(slam_ctx* ctx, const double* pts0, const double* pts1, int N,
                    double* F, double* E, double* pose, double* X, uint8_t* good, double* record,
                    int32_t* counts4, int32_t* winner);
 
-/* A batch of independent pairs in one call: one upload, one download, one synchronisation; the pairs' kernels are
- * spread over the context's internal streams.  pts0/pts1: the pairs' matches concatenated, (offsets[P], 2);
+/* A batch of independent pairs in one call: one upload, one download, one synchronisation, and ONE launch per
+ * pipeline stage for the whole batch on the context's stream (every kernel picks its pair with blockIdx.y; the fused
+ * RANSAC kernel is launched once per scoring shape present, at most three times).  The large per-match outputs X and
+ * good are copied straight into the caller's arrays (page-locked arrays from slam_host_alloc transfer fastest); the
+ * results are complete when the call returns.  pts0/pts1: the pairs' matches concatenated, (offsets[P], 2);
  * pair p owns rows offsets[p] .. offsets[p+1]-1 (at least 8).  Outputs as slam_init_pair, per pair: F, E (P x 9),
  * pose (P x 16), record (P x 12), counts4 (P x 4), winner (P); per match: X (offsets[P] x 3), good (offsets[P]).
  * Any output may be NULL.  Results are bit-identical to P calls of slam_init_pair. */

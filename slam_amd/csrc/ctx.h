@@ -37,6 +37,7 @@ struct slam_ctx {
     unsigned next_lane = 0;
     int lanes_in_use = 1;               // slam_set_concurrency
     bool sampson = false;               // slam_set_scoring
+    bool inject_sampler_fault = false;  // SLAM_AMD_FAULT_INJECT=sampler (tests of the SLAM_ESAMPLER path)
     char err[512] = {0};
 
     // device scratch (grown on demand, never shrunk)

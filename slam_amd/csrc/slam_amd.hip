@@ -48,7 +48,7 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     ctx->device = device;
     auto fail = [&](const char* what, hipError_t err) {
         snprintf(g_create_err, sizeof g_create_err, "%s: %s", what, hipGetErrorString(err));
-        delete ctx;
+        slam_destroy(ctx);  // releases the streams and pinned buffers created so far
         return SLAM_EHIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
@@ -68,10 +68,13 @@ extern "C" int slam_create(int device, slam_ctx** out) {
         else if (!strcmp(want, "low")) prio = prio_least;
         else if (strcmp(want, "high")) {
             snprintf(g_create_err, sizeof g_create_err, "SLAM_AMD_STREAM_PRIORITY=%s: expected high, normal or low", want);
-            delete ctx;
+            slam_destroy(ctx);
             return SLAM_EINVAL;
         }
     }
+    // test hook: SLAM_AMD_FAULT_INJECT=sampler makes the MT19937 table useless (all words rejected), so that the
+    // SLAM_ESAMPLER path of every entry point can be exercised
+    if (const char* inject = getenv("SLAM_AMD_FAULT_INJECT")) ctx->inject_sampler_fault = !strcmp(inject, "sampler");
     if ((e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio)) != hipSuccess)
         return fail("hipStreamCreate", e);
     ctx->stream = ctx->cur = ctx->own_stream;
@@ -88,7 +91,7 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->small, 1024 * sizeof(double));
     if (rc != SLAM_OK) {
         snprintf(g_create_err, sizeof g_create_err, "%s", ctx->err);
-        delete ctx;
+        slam_destroy(ctx);
         return rc;
     }
     if ((e = hipMemsetAsync(ctx->flags.p, 0, 16 * sizeof(int32_t), ctx->stream)) != hipSuccess)
@@ -101,7 +104,7 @@ extern "C" int slam_create(int device, slam_ctx** out) {
 extern "C" void slam_destroy(slam_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)slam_sync_all(ctx);
+    if (ctx->stream) (void)slam_sync_all(ctx);  // a context that failed half-way through slam_create has no stream yet
     slam_buf* bufs[] = {&ctx->pts, &ctx->norm, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
                         &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track, &ctx->match, &ctx->batch};
     for (slam_buf* b : bufs)
@@ -172,9 +175,13 @@ extern "C" int slam_set_scoring(slam_ctx* ctx, int mode) {
     return SLAM_OK;
 }
 
+static int check_flags(slam_ctx* ctx);
+
 extern "C" int slam_synchronize(slam_ctx* ctx) {
     if (!ctx) return SLAM_EINVAL;
-    return slam_sync_all(ctx);
+    SLAM_TRY(slam_sync_all(ctx));
+    // the asynchronous entry points cannot report a sampler that ran out of words when they return: it shows here
+    return check_flags(ctx);
 }
 
 // ================================================================================================
@@ -307,7 +314,12 @@ int slam_fill_raw_table(slam_ctx* ctx, uint64_t seed, int64_t it0, int64_t n) {
         }
         for (auto& th : pool) th.join();
     }
+    if (ctx->inject_sampler_fault) std::fill(host.begin(), host.end(), 0xFFFFFFFFu);  // every word rejected by every N
     ctx->raw_n = 0;
+    // Kernels queued earlier on ANY of the context's streams index the table with the old first iteration: they must
+    // have finished before the rows are replaced in place (growing the buffer synchronises too, a refill that fits
+    // the capacity would not).
+    SLAM_TRY(slam_sync_all(ctx));
     SLAM_TRY(slam_reserve(ctx, ctx->raw, host.size() * sizeof(uint32_t)));
     SLAM_HIP(ctx, hipMemcpyAsync(ctx->raw.p, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
                                  ctx->stream));
@@ -1060,6 +1072,10 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
         }
         class_begin[cls + 1] = (int)grouped.size();
     }
+    // From here on copies from and to function-local vectors are in flight: whatever fails below, the stream is
+    // drained before the vectors go out of scope.
+    std::vector<double> hb((size_t)P * PB_LEN);
+    auto enqueue_and_wait = [&]() -> int {
     SLAM_HIP(ctx, hipMemcpyAsync(r0, pts0, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(r1, pts1, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
     SLAM_HIP(ctx, hipMemcpyAsync(d_args, args.data(), (size_t)P * sizeof(PairArgs), hipMemcpyHostToDevice, ctx->stream));
@@ -1101,11 +1117,16 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
     SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(eb, P), dim3(256), 0, (const double*)nullptr,
                          (const unsigned long long*)nullptr, (const double*)nullptr, (int64_t)0, (double*)nullptr,
                          (int32_t*)nullptr, (double*)nullptr, (uint8_t*)nullptr, all));
-    std::vector<double> hb((size_t)P * PB_LEN);
     SLAM_HIP(ctx, hipMemcpyAsync(hb.data(), blocks, hb.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (X) SLAM_HIP(ctx, hipMemcpyAsync(X, dX, (size_t)total * 24, hipMemcpyDeviceToHost, ctx->stream));
     if (good) SLAM_HIP(ctx, hipMemcpyAsync(good, dmask, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_TRY(check_flags(ctx));
+    return check_flags(ctx);  // synchronises
+    };
+    const int rc_batch = enqueue_and_wait();
+    if (rc_batch != SLAM_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc_batch;
+    }
     for (int p = 0; p < P; ++p) {
         const double* blk = hb.data() + (size_t)p * PB_LEN;
         if (E) memcpy(E + 9 * (size_t)p, blk + PB_PW + PW_E, 9 * sizeof(double));

@@ -50,8 +50,8 @@ def initialise_pair(img0_points, img1_points, intrinsic_camera_matrix, iteration
 
 
 def initialise_pairs(pairs, intrinsic_camera_matrix, iterations=1000, ctx=None):
-    """initialise_pair for a batch of independent pairs in one library call (one upload, one download; the pairs'
-    kernels overlap on the context's internal streams).  pairs: sequence of (img0_points, img1_points).
+    """initialise_pair for a batch of independent pairs in one library call (one upload, one download, one launch per
+    pipeline stage for the whole batch; complete on return).  pairs: sequence of (img0_points, img1_points).
     Returns a list of the dicts initialise_pair returns, bit-identical to calling it pair by pair."""
     K = f64(intrinsic_camera_matrix)
     a = [f64(np.asarray(p0)) for p0, _ in pairs]

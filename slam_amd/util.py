@@ -47,3 +47,17 @@ def rq_decomposition(m):
     flip = np.eye(m.shape[0])[::-1]
     q_, r_ = np.linalg.qr(flip @ m)
     return flip @ r_.T @ flip, flip @ q_.T
+
+
+def collect_symbolic_equation_with_respect_to_vars(eq, vars):
+    """Coefficients of a sympy expression as a polynomial in `vars`: {monomial: coefficient}
+    (reference: src/util.py:45-57; only the reference's symbolic research scripts use it)."""
+    assert isinstance(vars, list)
+    eq = eq.expand()
+    if not vars:
+        return {1: eq}
+    out = {}
+    for power, rest in eq.collect(vars[0], evaluate=False).items():
+        for sub_power, coeff in collect_symbolic_equation_with_respect_to_vars(rest, vars[1:]).items():
+            out[power * sub_power] = coeff
+    return out

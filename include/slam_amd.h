@@ -110,6 +110,24 @@ int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, int N, cons
 int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                       int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
                       uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all);
+/* slam_ransac_f_dev for callers that cannot allocate.  No counterpart in the reference: it exists for code that runs
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  The call allocates nothing on the
+ * device or through the HIP runtime, frees nothing and synchronises nothing: the per-hypothesis scratch (F, inlier
+ * counts, inlier-error sums) lives in a device array that is part of the library's code object (1.3 MiB per GPU, held
+ * until the process ends).  Differences from slam_ransac_f_dev:
+ *  - H <= SLAM_NOALLOC_MAX_H, otherwise SLAM_EINVAL (split a longer range into several calls and merge the records
+ *    with slam_merge_records);
+ *  - the per-hypothesis outputs are not available (they are the scratch);
+ *  - with d_idx == NULL and SLAM_SAMPLER_CPYTHON the context's MT19937 word table must already cover
+ *    [it0, it0 + H) for this seed (any earlier call with that seed and range made it); otherwise SLAM_EINVAL.
+ *    Pre-drawn indices and the counter-based sampler need no table;
+ *  - always on the context's ordered stream (slam_set_concurrency does not apply).
+ * Every call on one GPU shares that GPU's array, from whatever context: calls that overlap on one GPU (two contexts,
+ * or two streams set with slam_set_stream) race.  Results are bit-identical to slam_ransac_f_dev's. */
+#define SLAM_NOALLOC_MAX_H 16384
+int slam_ransac_f_dev_noalloc(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
+                              int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
+                              uint8_t* d_mask);
 /* A prepared slam_ransac_f_dev call.  The arguments are checked and stored once; slam_job_run enqueues the same work
  * again, exactly as slam_ransac_f_dev would (including the rotation over the context's internal streams).  For
  * callers whose per-call argument marshalling is a cost of its own (ctypes spends 2 us on the 15 arguments, as much as

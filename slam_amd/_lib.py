@@ -19,6 +19,7 @@ REC_COUNT, REC_ERRSUM, REC_INDEX, REC_F, REC_LEN = 0, 1, 2, 3, 12
 SAMPLER_CPYTHON, SAMPLER_COUNTER = 0, 1
 SEED_BASE = 0x1337BEEF
 DEFAULT_THRESHOLD = 0.005
+NOALLOC_MAX_H = 16384
 SCORE_ALGEBRAIC, SCORE_SAMPSON = 0, 1
 K_SOLVE, K_SCORE, K_SELECT, K_TRIANGULATE, K_RESECT, K_TRACK_SCORE, K_MATCH = 0, 1, 2, 3, 4, 5, 6
 
@@ -39,6 +40,7 @@ SIGNATURES = {
     "slam_eightpoint": (_int, [_vp, _vp, _vp, _int, _vp]),
     "slam_ransac_f": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
     "slam_ransac_f_dev": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "slam_ransac_f_dev_noalloc": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp]),
     "slam_ransac_job_create": (_int, [_vp, _vp, _vp, _int, _vp, _int, _u64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp,
                                       C.POINTER(_vp)]),
     "slam_job_run": (_int, [_vp]),

@@ -71,6 +71,8 @@ struct slam_ctx {
     char* h_stage = nullptr;
     size_t h_stage_cap = 0;
 
+    unsigned char* noalloc_scratch = nullptr;  // this device's address of the code object's scratch array
+
     bool profiling = false;
     slam_prof prof;
 };

@@ -17,6 +17,16 @@ using namespace slamk;
 
 static char g_create_err[512] = "";
 
+// Hypothesis scratch of slam_ransac_f_dev_noalloc: F (H x 9 f64), inlier-error sums (H f64) and inlier counts (H i32)
+// for at most SLAM_NOALLOC_MAX_H hypotheses, in device memory that belongs to the code object, so that the entry
+// point needs no allocation.  Every GPU the library runs on holds its own copy (1.3 MiB) until the process ends.
+// In host code the array's NAME is not a device address: slam_create asks hipGetSymbolAddress for this device's
+// copy and keeps the pointer in the context; host code uses that pointer only.
+#define SLAM_NOALLOC_F_BYTES ((size_t)SLAM_NOALLOC_MAX_H * 9 * sizeof(double))
+#define SLAM_NOALLOC_E_BYTES ((size_t)SLAM_NOALLOC_MAX_H * sizeof(double))
+#define SLAM_NOALLOC_C_BYTES ((size_t)SLAM_NOALLOC_MAX_H * sizeof(int32_t))
+static __device__ __align__(256) unsigned char scratch[SLAM_NOALLOC_F_BYTES + SLAM_NOALLOC_E_BYTES + SLAM_NOALLOC_C_BYTES];
+
 // ================================================================================================
 // lifecycle
 // ================================================================================================
@@ -86,6 +96,9 @@ extern "C" int slam_create(int device, slam_ctx** out) {
         return fail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&ctx->h_flags, 16 * sizeof(int32_t), hipHostMallocDefault)) != hipSuccess)
         return fail("hipHostMalloc", e);
+    // this device's copy of the code object's scratch array (the device is current here)
+    if ((e = hipGetSymbolAddress((void**)&ctx->noalloc_scratch, HIP_SYMBOL(scratch))) != hipSuccess)
+        return fail("hipGetSymbolAddress(scratch)", e);
     int rc = slam_reserve(ctx, ctx->flags, 16 * sizeof(int32_t));
     if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->record, 64 * sizeof(double));
     if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->small, 1024 * sizeof(double));
@@ -515,6 +528,46 @@ extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double
     const int rc = ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
                                   d_errsums, d_F_all);
     ctx->cur = ctx->stream;
+    return rc;
+}
+
+// The same call for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid it): the
+// per-hypothesis scratch lives in the code object's `scratch` array instead of context buffers that grow on demand.
+// No hipMalloc / hipFree, no host-side table generation, nothing synchronises; always on the context's ordered stream.
+extern "C" int slam_ransac_f_dev_noalloc(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N,
+                                         const int32_t* d_idx, int sampler, uint64_t seed, int64_t it0, int H,
+                                         double threshold, double* d_record, uint8_t* d_mask) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, H >= 1, "H < 1");
+    if (H > SLAM_NOALLOC_MAX_H) {
+        snprintf(ctx->err, sizeof ctx->err,
+                 "invalid argument: slam_ransac_f_dev_noalloc scores at most %d hypotheses per call (H = %d); split the "
+                 "range into several calls or use slam_ransac_f_dev",
+                 SLAM_NOALLOC_MAX_H, H);
+        return SLAM_EINVAL;
+    }
+    SLAM_REQUIRE(ctx, ctx->noalloc_scratch != nullptr, "the context has no scratch pointer");
+    if (!d_idx && sampler == SLAM_SAMPLER_CPYTHON) {
+        // the MT19937 word table is generated on the host and uploaded into a buffer that may have to grow: not here
+        const bool covered = ctx->raw_n > 0 && ctx->raw_seed == seed && it0 >= ctx->raw_it0 &&
+                             it0 + H <= ctx->raw_it0 + ctx->raw_n;
+        SLAM_REQUIRE(ctx, covered,
+                     "slam_ransac_f_dev_noalloc: the CPython-compatible sampler needs its word table for this seed and "
+                     "iteration range to exist already (made by any earlier call with the same seed that covered the "
+                     "range); pass pre-drawn indices or use the counter-based sampler otherwise");
+    }
+    unsigned char* base = ctx->noalloc_scratch;  // device address from hipGetSymbolAddress, never the array's name
+    double* d_F_all = (double*)base;
+    double* d_errsums = (double*)(base + SLAM_NOALLOC_F_BYTES);
+    int32_t* d_counts = (int32_t*)(base + SLAM_NOALLOC_F_BYTES + SLAM_NOALLOC_E_BYTES);
+    // Nothing in the scratch has to start at zero: every launch writes F, count and sum of each of its H hypotheses
+    // before the selection kernel reads them, and reads no entry beyond H.
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;  // the timing helper may synchronise when its event pool wraps
+    ctx->cur = ctx->stream;
+    const int rc = ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
+                                  d_errsums, d_F_all);
+    ctx->profiling = prof;
     return rc;
 }
 

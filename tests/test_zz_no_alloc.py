@@ -1,0 +1,78 @@
+"""slam_ransac_f_dev_noalloc (the entry point for callers that cannot allocate) against slam_ransac_f_dev, through the
+C ABI: bit-identical record and mask, two calls in a row, the second on a smaller input; the size limit is enforced.
+
+Collected last on purpose (the file name sorts after every other test file)."""
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as so
+from slam_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair_on_device(torch, dev, N, seed):
+    d = synth.make_pair(N, 0.3, seed=seed)
+    n0, _ = so.normalize_points(d["pts0"])
+    n1, _ = so.normalize_points(d["pts1"])
+    return torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+
+
+def _both(ctx, torch, dev, p0, p1, N, H, sampler, seed, it0=0, d_idx=None):
+    lib = ctx.lib
+    out = []
+    for fn, extra in ((lib.slam_ransac_f_dev, (None, None, None)), (lib.slam_ransac_f_dev_noalloc, ())):
+        rec = torch.full((_lib.REC_LEN,), -7.0, dtype=torch.float64, device=dev)
+        mask = torch.full((N,), 9, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.check(fn(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None if d_idx is None else d_idx.data_ptr(), sampler, seed,
+                     it0, H, 0.005, rec.data_ptr(), mask.data_ptr(), *extra))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        out.append((rec.cpu().numpy(), mask.cpu().numpy()))
+    return out
+
+
+def test_noalloc_entry_point_equals_the_allocating_one():
+    import torch
+    ctx = _lib.default_context()
+    dev = torch.device("cuda", ctx.device)
+    # first call: the benchmark shape (fused kernel), CPython-compatible sampler; the allocating call comes first and
+    # leaves the sampler's word table behind, which the second form then finds
+    p0, p1 = _pair_on_device(torch, dev, 4096, 41)
+    (r_a, m_a), (r_b, m_b) = _both(ctx, torch, dev, p0, p1, 4096, 2048, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE)
+    assert np.array_equal(r_a, r_b) and np.array_equal(m_a, m_b)
+    assert r_b[_lib.REC_COUNT] == m_b.sum() and set(np.unique(m_b)) <= {0, 1}
+    # second call in a row, smaller input (another scoring shape), counter-based sampler: stale scratch must not leak
+    q0, q1 = _pair_on_device(torch, dev, 700, 42)
+    (r_a, m_a), (r_b, m_b) = _both(ctx, torch, dev, q0, q1, 700, 300, _lib.SAMPLER_COUNTER, 99, it0=1000)
+    assert np.array_equal(r_a, r_b) and np.array_equal(m_a, m_b)
+    assert r_b[_lib.REC_COUNT] == m_b.sum() and 1000 <= r_b[_lib.REC_INDEX] < 1300
+    # the largest call it takes (split solve / score / select path), pre-drawn indices
+    H = _lib.NOALLOC_MAX_H
+    idx = np.empty((H, 8), dtype=np.int32)
+    ctx.check(ctx.lib.slam_sample_indices(ctx.handle, _lib.SAMPLER_COUNTER, 5, 0, H, 4096, 8, _lib.ptr(idx)))
+    d_idx = torch.from_numpy(idx).to(dev)
+    (r_a, m_a), (r_b, m_b) = _both(ctx, torch, dev, p0, p1, 4096, H, _lib.SAMPLER_COUNTER, 5, d_idx=d_idx)
+    assert np.array_equal(r_a, r_b) and np.array_equal(m_a, m_b)
+    # and a small one again after the large one
+    (r_a, m_a), (r_b, m_b) = _both(ctx, torch, dev, q0, q1, 700, 8, _lib.SAMPLER_COUNTER, 99)
+    assert np.array_equal(r_a, r_b) and np.array_equal(m_a, m_b)
+
+
+def test_noalloc_entry_point_rejects_what_it_cannot_do():
+    import torch
+    ctx = _lib.default_context()
+    dev = torch.device("cuda", ctx.device)
+    p0, p1 = _pair_on_device(torch, dev, 512, 43)
+    rec = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    lib = ctx.lib
+    args = (ctx.handle, p0.data_ptr(), p1.data_ptr(), 512, None)
+    rc = lib.slam_ransac_f_dev_noalloc(*args, _lib.SAMPLER_COUNTER, 1, 0, _lib.NOALLOC_MAX_H + 1, 0.005, rec.data_ptr(), None)
+    assert rc == -1 and b"at most" in lib.slam_last_error(ctx.handle)
+    # CPython-compatible sampler with a seed whose word table nobody has made: refused, not generated
+    rc = lib.slam_ransac_f_dev_noalloc(*args, _lib.SAMPLER_CPYTHON, 0xDEADBEEF, 0, 64, 0.005, rec.data_ptr(), None)
+    assert rc == -1 and b"word table" in lib.slam_last_error(ctx.handle)
+    # the context is still fine afterwards
+    rc = lib.slam_ransac_f_dev_noalloc(*args, _lib.SAMPLER_COUNTER, 1, 0, 64, 0.005, rec.data_ptr(), None)
+    assert rc == 0 and lib.slam_synchronize(ctx.handle) == 0
+    assert rec.cpu().numpy()[_lib.REC_COUNT] >= 8

@@ -254,7 +254,7 @@ def main():
         tfl = FLOP_PER_EVAL * HL * N_MATCHES / (sc_us * 1e-6) / 1e12
         out["aux_large_h"] = {"workload": "same pair, 65536 hypotheses (counter-based sampler), split solve/score/select path",
                               "hypotheses_per_sec": HL / bdt, "residual_evals_per_sec": HL * N_MATCHES / bdt,
-                              "roofline": {"kernel": "k_score", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
+                              "roofline": {"kernel": "k_score_lds", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
                                            "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": tfl / PEAK_FP32_VALU,
                                            "avg_launch_us": sc_us}}
         # the same 65536 hypotheses scored with the Sampson distance (optional mode, not the reference's residual)

@@ -30,6 +30,7 @@ struct slam_prof {
 
 struct slam_ctx {
     int device = 0;
+    int num_cus = 256;                  // compute units of the device
     hipStream_t own_stream = nullptr;   // lane 0
     hipStream_t stream = nullptr;       // the context's ordered stream: own_stream, or the caller's (slam_set_stream)
     hipStream_t cur = nullptr;          // stream the launch helper uses right now (stream, or a lane)
@@ -58,6 +59,7 @@ struct slam_ctx {
     slam_buf track;     // tracking step: work block + per-hypothesis blocks
     slam_buf batch;     // slam_init_pairs: all pairs' points, planes and per-pair blocks
     hipEvent_t lane_event[SLAM_LANES + 1] = {};  // created on first use
+    slam_buf score_parts[SLAM_LANES];   // per-chunk partial counts and sums of the scoring kernel (N beyond one chunk)
     slam_buf select_parts[SLAM_LANES];  // range winners of the two-stage selection (large H), per internal stream
     slam_buf match;     // descriptor matching: per-slice candidate keys, staged descriptors and points
     uint64_t raw_seed = 0;

@@ -62,7 +62,25 @@ __device__ long long g_wg_log[SLAM_WG_LOG_MAX * 4];
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
 #endif
+// per-wave stamps of the large-H scoring kernel: row = workgroup * 16 + wave (rows beyond 4095 are dropped)
+#define SLAM_STAMP_WAVE(slot, value)                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        const int row_ = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);                              \
+        if ((threadIdx.x & 63) == 0 && row_ < 4096) g_stamps[row_ * 8 + (slot)] = (value);            \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+// per-wave stamps of the fused kernel's score phase: row = 1024 + workgroup * 8 + wave, workgroups 0..255
+#define SLAM_STAMP_W8(slot)                                                                           \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                                              \
+            g_stamps[(1024 + (int)blockIdx.x * 8 + (int)(threadIdx.x >> 6)) * 8 + (slot)] = clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
 #else
+#define SLAM_STAMP_W8(slot) do { } while (0)
+#define SLAM_STAMP_WAVE(slot, value) do { } while (0)
 #define SLAM_STAMP(slot) do { } while (0)
 #define SLAM_STAMP_SELECT(slot) do { } while (0)
 #define SLAM_WG_LOG_BEGIN() do { } while (0)
@@ -399,25 +417,32 @@ __global__ __launch_bounds__(64) void k_solve(const double2* __restrict__ p0, co
 //   r = (x1^T F) x0 with x = (u, v, 1); err = r^2; inlier iff err < thr (strict); count and sum of inlier err.
 // The test fl(r*r) < thr is evaluated as |r| < rcut, which is the same predicate for every double r because the
 // rounded square is monotone in |r| (rcut is found on the host: square_cutoff()); the sum adds r*r by fma.
-// A workgroup of WAVES waves scores HB hypotheses (F in LDS) against ALL N matches: each lane keeps PPL matches of
-// a chunk of 64*WAVES*PPL in registers and loops over the hypotheses.  Per-hypothesis sums are combined in a
-// fixed order (lane partials over chunks, wave_sum_f64 over the 64 lanes, waves in order) that depends on N only,
-// so a hypothesis gets the same errsum whichever kernel, workgroup, launch or GPU scores it.
+//
+// Order of the inlier-error sum of one hypothesis (it fixes the bits, so every kernel below follows it and a
+// hypothesis gets the same sum whichever kernel, workgroup, launch or GPU scores it).  PPL (matches per lane) is a
+// function of N alone (1, 4 or 8); the matches are cut into chunks of 512*PPL; inside a chunk, match
+// i = k*512 + w*64 + l belongs to slice w (0..7), lane position l (0..63), turn k (0..PPL-1):
+//   p(w,l) = sum over k in order of r^2            (a chain of fma starting from 0, inliers only)
+//   t(l)   = sum over w in order of p(w,l)
+//   chunk  = tree over l of t(l): lanes l^1, then l^2, then 7-l within 8, then 15-l within 16, then rows of 16 as
+//            (r0 + r1) + (r2 + r3)                 (wave_sum_f64 and the multi-value forms below build exactly it)
+//   errsum = sum over chunks in order.
 // ------------------------------------------------------------------------------------------------
+#define SLAM_SLICES 8  // slices of 64 lane positions per turn: the eight waves of the fused kernel's workgroup
+
 template <int PPL, int WAVES>
 struct MatchChunk {  // PPL matches per lane of a chunk of 64*WAVES*PPL, plus which of them are real
     double a0[PPL], a1[PPL], b0[PPL], b1[PPL];
-    bool live[PPL];
-    unsigned long long livemask[PPL];  // the same as wave-uniform lane masks
+    unsigned long long livemask[PPL];  // wave-uniform lane masks of the real matches
     __device__ __forceinline__ void load(const double2* __restrict__ p0, const double2* __restrict__ p1, int N, int base) {
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
             const int i = base + k * 64 * WAVES + (int)threadIdx.x;
-            live[k] = i < N;
-            livemask[k] = __ballot(live[k]);
+            const bool live = i < N;
+            livemask[k] = __ballot(live);
             // one 32-bit byte offset serves both arrays (scalar base + vector offset addressing; the callers keep
             // N below 2^27 matches)
-            const uint32_t off = (uint32_t)(live[k] ? i : N - 1) * (uint32_t)sizeof(double2);
+            const uint32_t off = (uint32_t)(live ? i : N - 1) * (uint32_t)sizeof(double2);
             const double2 a = *(const double2*)((const char*)p0 + off), b = *(const double2*)((const char*)p1 + off);
             a0[k] = a.x; a1[k] = a.y; b0[k] = b.x; b1[k] = b.y;
         }
@@ -434,106 +459,305 @@ __device__ __forceinline__ double sampson_error(double r, double l0, double l1, 
     return (r * r) * fast_rcp(den);
 }
 
+// residual of one match against one F (and, in Sampson mode, the distance in its place)
+template <bool SAMPSON>
+__device__ __forceinline__ double residual(double a0, double a1, double b0, double b1, double f00, double f01, double f02,
+                                           double f10, double f11, double f12, double f20, double f21, double f22) {
+    const double l0 = fma(b0, f00, fma(b1, f10, f20));
+    const double l1 = fma(b0, f01, fma(b1, f11, f21));
+    const double l2 = fma(b0, f02, fma(b1, f12, f22));
+    const double r = fma(l0, a0, fma(l1, a1, l2));
+    if (SAMPSON) return sampson_error(r, l0, l1, a0, a1, f00, f01, f02, f10, f11, f12);
+    return r;
+}
+
+// es += (|r| < rcut on the lanes of `live`) ? r*r : 0; returns the number of those lanes.
+// fl(r*r) < thr  <=>  |r| < rcut (rcut: the smallest double whose rounded square reaches thr).  The compare runs on
+// the real matches only and writes the execution mask itself (and the same bits to a scalar pair), so the inlier lanes
+// alone accumulate r*r: no select instructions, and no scalar instruction between the compare and the accumulation.
+// The population count of the scalar copy is the inlier count (one scalar instruction, kept here so that the mask
+// does not have to stay alive).
+__device__ __forceinline__ int accumulate_inliers(double r, double rcut, unsigned long long live,
+                                                  unsigned long long full_exec, double& es) {
+    unsigned long long lt_mask;
+    int n;
+    asm volatile(
+        "s_mov_b64 exec, %[live]\n\t"
+        "v_cmpx_lt_f64_e64 %[lt], |%[r]|, %[rc]\n\t"
+        "v_fma_f64 %[es], %[r], %[r], %[es]\n\t"
+        "s_mov_b64 exec, %[full]\n\t"
+        "s_bcnt1_i32_b64 %[n], %[lt]"
+        : [es] "+v"(es), [lt] "=&s"(lt_mask), [n] "=&s"(n)  // written before the inputs are all read
+        : [r] "v"(r), [rc] "s"(rcut), [live] "s"(live), [full] "s"(full_exec)
+        : "scc");
+    return n;
+}
+
+// Sampson mode: r is the distance itself, added as it is
+__device__ __forceinline__ int accumulate_inliers_sampson(double d, double cut, unsigned long long live, double& es) {
+    const bool in = d < cut;
+    const unsigned long long m = __ballot(in) & live;
+    es += (((m >> (threadIdx.x & 63)) & 1ull) != 0) ? d : 0.0;
+    return __popcll(m);
+}
+
+// lane mask of the n lowest lanes (all for n >= 64, none for n <= 0); n is wave-uniform.  Scalar instructions only.
+__device__ __forceinline__ unsigned long long low_lanes_mask(int n) {
+    unsigned long long m;
+    int t;
+    asm("s_max_i32 %[t], %[n], 0\n\t"
+        "s_bfm_b64 %[m], %[t], 0\n\t"      // ((1 << t[5:0]) - 1) << 0
+        "s_cmp_ge_i32 %[n], 64\n\t"
+        "s_cselect_b64 %[m], -1, %[m]"
+        : [m] "=&s"(m), [t] "=&s"(t)
+        : [n] "s"(n)
+        : "scc");
+    return m;
+}
+
+// Score phase of the fused kernel.  A workgroup of eight waves scores HB = 8 hypotheses (F in LDS) against ALL N
+// matches: wave w owns slice w of every chunk, each lane keeps PPL matches of the chunk in registers and loops over
+// the hypotheses.  The lanes' partial sums p(w,l) of the eight hypotheses meet in LDS; wave j then adds the slices of
+// hypothesis j in order and reduces over the lanes.
 template <int HB, int PPL, int WAVES, bool SAMPSON>
 __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
                                                  MatchChunk<PPL, WAVES>& m, const double (*s_F)[9], double rcut,
                                                  int h0, int H, int32_t* __restrict__ counts,
-                                                 double* __restrict__ errsums, double (*s_err)[WAVES],
+                                                 double* __restrict__ errsums, double (*s_part)[WAVES][64],
                                                  int (*s_cnt)[WAVES]) {
+    static_assert(HB == 8 && WAVES == SLAM_SLICES, "wave j folds hypothesis j; the slices are the eight waves");
     constexpr int THREADS = 64 * WAVES;
-    const int tid = threadIdx.x;
-    double es[HB];
-    int cnt[HB];  // wave-uniform: ballot popcounts
-#pragma unroll
-    for (int j = 0; j < HB; ++j) { es[j] = 0.0; cnt[j] = 0; }
-
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // (the lane number is recomputed where it is needed instead of being kept in a register across the loop)
     const unsigned long long full_exec = __ballot(true);  // every lane of the workgroup is active here
+    double total = 0.0;   // of hypothesis `wave`, over the chunks so far (the same on every lane)
+    int ctotal = 0;
     // m holds the first chunk on entry and is refilled for the following ones
     for (int base = 0; base < N; base += THREADS * PPL) {
-        if (base > 0) m.load(p0, p1, N, base);
+        if (base > 0) {
+            __syncthreads();  // the previous chunk's partial sums have been read
+            m.load(p0, p1, N, base);
+        }
+        int cnt[HB];  // wave-uniform: ballot popcounts
+        SLAM_STAMP_W8(0);
+        // F of the next hypothesis is fetched from LDS while the current one is scored (its latency would otherwise
+        // be paid eight times per chunk by a wave that shares its SIMD with one other wave only)
+        double fc[9], fn[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) fc[q] = s_F[0][q];
 #pragma unroll
         for (int j = 0; j < HB; ++j) {
-            // keep each hypothesis' F loads next to their use: hoisting all of them costs 144 registers
-            asm volatile("" ::: "memory");
-            const double f00 = s_F[j][0], f01 = s_F[j][1], f02 = s_F[j][2], f10 = s_F[j][3], f11 = s_F[j][4],
-                         f12 = s_F[j][5], f20 = s_F[j][6], f21 = s_F[j][7], f22 = s_F[j][8];
-            // residuals of the PPL matches first (independent chains), then the masked accumulation
-            double r[PPL];
+            if (j + 1 < HB) {
 #pragma unroll
-            for (int k = 0; k < PPL; ++k) {
-                const double l0 = fma(m.b0[k], f00, fma(m.b1[k], f10, f20));
-                const double l1 = fma(m.b0[k], f01, fma(m.b1[k], f11, f21));
-                const double l2 = fma(m.b0[k], f02, fma(m.b1[k], f12, f22));
-                r[k] = fma(l0, m.a0[k], fma(l1, m.a1[k], l2));
-                if (SAMPSON) r[k] = sampson_error(r[k], l0, l1, m.a0[k], m.a1[k], f00, f01, f02, f10, f11, f12);
+                for (int q = 0; q < 9; ++q) fn[q] = s_F[j + 1][q];
             }
+            asm volatile("" ::: "memory");  // later hypotheses' F loads stay below: hoisting all of them costs 144 registers
+            // The two waves of a SIMD issue oldest first; left alone, the older wave runs at the rate of a wave that
+            // has the SIMD to itself and the younger one finishes its last third alone, at that same (slower) rate.
+            // The wave that is behind gets the higher priority, so both stay within two hypotheses of each other.
+            if (j < 2) __builtin_amdgcn_s_setprio(3);       // (the loop is unrolled: one of these remains per turn)
+            else if (j < 4) __builtin_amdgcn_s_setprio(2);
+            else if (j < 6) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            double es = 0.0;
+            cnt[j] = 0;
+            // two matches at a time: both residuals first (independent chains), then the masked accumulations in order
+            constexpr int KB = PPL >= 2 ? 2 : 1;
 #pragma unroll
-            for (int k = 0; k < PPL; ++k) {
-                if (SAMPSON) {
-                    // r[k] is the Sampson distance and rcut the threshold on it
-                    const bool in = m.live[k] && r[k] < rcut;
-                    cnt[j] += __popcll(__ballot(in));
-                    es[j] += in ? r[k] : 0.0;
-                    continue;
-                }
-                // fl(r*r) < thr  <=>  |r| < rcut (rcut: the smallest double whose rounded square reaches thr).
-                // The compare runs on the real matches only and writes the execution mask itself (and the same bits
-                // to a scalar pair), so the inlier lanes alone accumulate r*r: no select instructions, and no scalar
-                // instruction between the compare and the accumulation.  The population count of the scalar copy is
-                // the inlier count; it is ordinary code that the compiler schedules wherever a slot is free.
-                unsigned long long lt_mask;
-                asm volatile(
-                    "s_mov_b64 exec, %[live]\n\t"
-                    "v_cmpx_lt_f64_e64 %[lt], |%[r]|, %[rc]\n\t"
-                    "v_fma_f64 %[es], %[r], %[r], %[es]\n\t"
-                    "s_mov_b64 exec, %[full]"
-                    : [es] "+v"(es[j]), [lt] "=&s"(lt_mask)  // written before the inputs are all read
-                    : [r] "v"(r[k]), [rc] "s"(rcut), [live] "s"(m.livemask[k]), [full] "s"(full_exec));
-                cnt[j] += __popcll(lt_mask);
+            for (int k0 = 0; k0 < PPL; k0 += KB) {
+                double r[KB];
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk)
+                    r[kk] = residual<SAMPSON>(m.a0[k0 + kk], m.a1[k0 + kk], m.b0[k0 + kk], m.b1[k0 + kk], fc[0], fc[1], fc[2],
+                                              fc[3], fc[4], fc[5], fc[6], fc[7], fc[8]);
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk)
+                    cnt[j] += SAMPSON ? accumulate_inliers_sampson(r[kk], rcut, m.livemask[k0 + kk], es)
+                                      : accumulate_inliers(r[kk], rcut, m.livemask[k0 + kk], full_exec, es);
+            }
+            {   // this lane's partial sum p(w,l) of hypothesis j
+                const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                s_part[j][wave][lane] = es;
+            }
+            if (j + 1 < HB) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) fc[q] = fn[q];
             }
         }
-    }
-    SLAM_STAMP(4);
-    const int wave = tid >> 6, lane = tid & 63;
-    static_assert(HB == 8, "the wave reduction handles eight hypotheses at a time");
-    {
-        const double s = wave_sum8_f64(es);
-        if (lane < 8) s_err[wave_sum8_slot(lane)][wave] = s;
+        SLAM_STAMP(4);
+        SLAM_STAMP_W8(1);
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < HB; ++j) s_cnt[j][wave] = cnt[j];
         }
-    }
-    SLAM_STAMP(6);
-    __syncthreads();
-    SLAM_STAMP(5);
-    if (tid < HB && h0 + tid < H) {
-        int c = 0;
-        double e = 0.0;
+        SLAM_STAMP(6);
+        __syncthreads();
+        SLAM_STAMP(5);
+        SLAM_STAMP_W8(2);
+        // hypothesis `wave`: the slices in order on every lane position, then the tree over the lane positions
+        double pw[WAVES];
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) { c += s_cnt[tid][w]; e += s_err[tid][w]; }
-        counts[h0 + tid] = c;
-        errsums[h0 + tid] = e;
+        for (int w = 0; w < WAVES; ++w) pw[w] = s_part[wave][w][lane];
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) c += s_cnt[wave][w];
+        double t = pw[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += pw[w];
+        total += wave_sum_f64(t);
+        ctotal += c;
+        SLAM_STAMP_W8(3);
+    }
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == 0 && h0 + wave < H) {
+        counts[h0 + wave] = ctotal;
+        errsums[h0 + wave] = total;
     }
 }
 
-// K2 standalone: F read from memory (large H, after k_solve)
-template <int HB, int PPL, int WAVES, bool SAMPSON>
-__global__ __launch_bounds__(64 * WAVES, 32 / WAVES) void k_score(const double2* __restrict__ p0, const double2* __restrict__ p1,
-                                                      int N, const double* __restrict__ Fall, int H, double rcut,
-                                                      int32_t* __restrict__ counts, double* __restrict__ errsums) {
-    __shared__ double s_F[HB][9];
-    __shared__ double s_err[HB][WAVES];
-    __shared__ int s_cnt[HB][WAVES];
-    const int h0 = blockIdx.x * HB;
-    MatchChunk<PPL, WAVES> first;
-    first.load(p0, p1, N, 0);
-    if (threadIdx.x < HB * 9) {
-        const int h = min(h0 + (int)threadIdx.x / 9, H - 1);  // surplus slots rescore the last hypothesis; dropped
-        s_F[threadIdx.x / 9][threadIdx.x % 9] = Fall[(size_t)h * 9 + threadIdx.x % 9];
+// K2 standalone (large H, after k_solve).  The matches of one chunk live in LDS for the whole life of the workgroup;
+// every WAVE scores hypotheses of its own, HG at a time with their F in registers, against all matches of the chunk:
+// no workgroup barrier and no exchange between waves in the loop, one wave reduction per HG hypotheses and chunk.
+// Work unit u = chunk * nslots + slot: the workgroup stages the chunk and its waves take the groups of HG hypotheses
+// g = slot * WAVES + wave, then + nslots * WAVES, ...  With one chunk (N <= 512*PPL) the results are final; with more,
+// out_counts / out_errsums are [chunk][H] partial tables that k_combine_chunks folds in chunk order.
+template <int HG>
+__device__ __forceinline__ double wave_sum_hg(const double (&v)[HG]);
+
+template <int HG, int PPL, int WAVES, bool SAMPSON>
+__global__ __launch_bounds__(64 * WAVES) void k_score_lds(const double2* __restrict__ p0, const double2* __restrict__ p1,
+                                                          int N, const double* __restrict__ Fall, int H, double rcut,
+                                                          int nchunks, int nslots, int32_t* __restrict__ out_counts,
+                                                          double* __restrict__ out_errsums) {
+    constexpr int CH = 64 * SLAM_SLICES * PPL, THREADS = 64 * WAVES;
+    static_assert(CH % THREADS == 0 || THREADS % CH == 0, "staging loop");
+    __shared__ double2 s_p0[CH];
+    __shared__ double2 s_p1[CH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long full_exec = __ballot(true);
+    const int ngroups = (H + HG - 1) / HG;
+    int vzero;  // a zero the compiler cannot see through: keeps the (wave-uniform) F loads on the vector side, so that
+                // the F values are VGPR operands and an FMA never needs two scalar operands
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    SLAM_STAMP_WAVE(0, clock64());
+    SLAM_STAMP_WAVE(6, wall_clock64());
+    int stamp_group = 0;
+    (void)stamp_group;
+    for (int u = blockIdx.x; u < nchunks * nslots; u += gridDim.x) {
+        const int chunk = __builtin_amdgcn_readfirstlane(u / nslots);  // (the division runs on the vector unit)
+        const int slot = u - chunk * nslots;
+        const int base = chunk * CH;
+        if (u != (int)blockIdx.x) __syncthreads();  // everybody has finished with the previous chunk
+        for (int q = tid; q < CH; q += THREADS) {
+            const int i = min(base + q, N - 1);
+            s_p0[q] = p0[i];
+            s_p1[q] = p1[i];
+        }
+        __syncthreads();
+        const int nlive = __builtin_amdgcn_readfirstlane(min(N - base, CH));  // real matches of this chunk
+        SLAM_STAMP_WAVE(1, clock64());
+        for (int g = slot * WAVES + wave; g < ngroups; g += nslots * WAVES) {
+            const int h0 = g * HG;
+            double f[HG][9];
+#pragma unroll
+            for (int h = 0; h < HG; ++h) {
+                // surplus slots rescore the last hypothesis.  The six entries that multiply come through scalar loads
+                // (wave-uniform address) and stay scalar operands; the three that start an FMA chain go to vector
+                // registers, because an FMA takes one scalar operand only.
+                const double* __restrict__ Fs = Fall + (size_t)min(h0 + h, H - 1) * 9;
+                const double* __restrict__ Fp = Fs + vzero;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) f[h][q] = Fs[q];
+#pragma unroll
+                for (int q = 6; q < 9; ++q) f[h][q] = Fp[q];
+            }
+            double t[HG];
+            int cnt[HG];
+#pragma unroll
+            for (int h = 0; h < HG; ++h) { t[h] = 0.0; cnt[h] = 0; }
+            // The four waves of a SIMD issue oldest first: left alone, the oldest wave would run through all of its
+            // groups and leave the youngest to finish by itself, at the rate one wave can issue.  A wave with more
+            // groups still to do gets the higher priority, so the waves of a SIMD stay within one group of each other.
+            {
+                const int left = (ngroups - 1 - g) / (nslots * WAVES);  // groups after this one
+                if (left >= 3) __builtin_amdgcn_s_setprio(3);
+                else if (left == 2) __builtin_amdgcn_s_setprio(2);
+                else if (left == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#pragma unroll 1
+            for (int w = 0; w < SLAM_SLICES; ++w) {
+                double p[HG];
+#pragma unroll
+                for (int h = 0; h < HG; ++h) p[h] = 0.0;
+                // two turns at a time: the residuals of both matches against the HG hypotheses first (2 * HG independent
+                // chains, so that a wave issues back to back even when it has its SIMD to itself), then the masked
+                // accumulations in the order of the sum (turn k before turn k + 1)
+                constexpr int KB = PPL >= 2 ? 2 : 1;
+#pragma unroll
+                for (int k0 = 0; k0 < PPL; k0 += KB) {
+                    double r[KB][HG];
+                    unsigned long long live[KB];
+#pragma unroll
+                    for (int kk = 0; kk < KB; ++kk) {
+                        const int first = (k0 + kk) * 64 * SLAM_SLICES + w * 64;  // local index of lane position 0
+                        const double2 a = s_p0[first + lane], b = s_p1[first + lane];
+                        live[kk] = low_lanes_mask(nlive - first);  // lanes whose match exists
+#pragma unroll
+                        for (int h = 0; h < HG; ++h)
+                            r[kk][h] = residual<SAMPSON>(a.x, a.y, b.x, b.y, f[h][0], f[h][1], f[h][2], f[h][3], f[h][4],
+                                                         f[h][5], f[h][6], f[h][7], f[h][8]);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                        for (int h = 0; h < HG; ++h)
+                            cnt[h] += SAMPSON ? accumulate_inliers_sampson(r[kk][h], rcut, live[kk], p[h])
+                                              : accumulate_inliers(r[kk][h], rcut, live[kk], full_exec, p[h]);
+                }
+#pragma unroll
+                for (int h = 0; h < HG; ++h) t[h] += p[h];
+            }
+            const double sum = wave_sum_hg<HG>(t);  // lane l < HG holds the total of hypothesis wave_sum_hg_slot(l)
+            if (lane < HG) {
+                const int slot_h = HG == 4 ? wave_sum4_slot(lane) : 0;
+                int c = cnt[0];
+#pragma unroll
+                for (int h = 1; h < HG; ++h) c = slot_h == h ? cnt[h] : c;
+                if (h0 + slot_h < H) {
+                    out_counts[(size_t)chunk * H + h0 + slot_h] = c;
+                    out_errsums[(size_t)chunk * H + h0 + slot_h] = sum;
+                }
+            }
+#ifdef SLAM_STAMPS
+            if (stamp_group < 3) SLAM_STAMP_WAVE(2 + stamp_group, clock64());
+            ++stamp_group;
+#endif
+        }
     }
-    __syncthreads();
-    score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
+    __builtin_amdgcn_s_setprio(0);
+    SLAM_STAMP_WAVE(5, clock64());
+    SLAM_STAMP_WAVE(7, wall_clock64());
+}
+
+template <>
+__device__ __forceinline__ double wave_sum_hg<4>(const double (&v)[4]) { return wave_sum4_f64(v); }
+template <>
+__device__ __forceinline__ double wave_sum_hg<1>(const double (&v)[1]) { return wave_sum_f64(v[0]); }
+
+// chunks of a hypothesis folded in order (N > 512*PPL): counts[h] = sum_c pc[c][h], errsums[h] = sum_c pe[c][h]
+__global__ __launch_bounds__(256) void k_combine_chunks(const int32_t* __restrict__ pc, const double* __restrict__ pe,
+                                                        int nchunks, int H, int32_t* __restrict__ counts,
+                                                        double* __restrict__ errsums) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= H) return;
+    int c = 0;
+    double e = 0.0;
+    for (int k = 0; k < nchunks; ++k) { c += pc[(size_t)k * H + h]; e += pe[(size_t)k * H + h]; }
+    counts[h] = c;
+    errsums[h] = e;
 }
 
 // K1+K2 fused for small H.  A workgroup of eight waves owns eight hypotheses:
@@ -562,7 +786,7 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
     }
     static_assert(HB == 8 && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves eight hypotheses, eight lanes each");
     __shared__ double s_F[HB][9];
-    __shared__ double s_err[HB][WAVES];
+    __shared__ double s_part[HB][WAVES][64];  // partial sums p(w,l) of the eight hypotheses
     __shared__ int s_cnt[HB][WAVES];
     __shared__ int32_t s_sel[HB][8];
     __shared__ int32_t s_scratch[HB][16];
@@ -612,7 +836,7 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
     }
     barrier_lds_only();
     SLAM_STAMP(3);
-    score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_err, s_cnt);
+    score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_part, s_cnt);
     SLAM_WG_LOG_END((unsigned long long)(uintptr_t)Fout);
 }
 

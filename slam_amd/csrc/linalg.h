@@ -637,4 +637,38 @@ __device__ __forceinline__ double wave_sum8_f64(const double (&v)[8]) {
     return t;
 }
 
+// The same for FOUR per-lane values: two halving steps (lane^1, lane^2), then the all-reduce steps of 8, 16, 32 and 64
+// lanes.  Returns the total of v[wave_sum4_slot(lane)]; lanes 0..3 cover slots {0,2,1,3}.  The summation tree of every
+// value is the one of wave_sum_f64 (additions commute, so which partner adds does not matter): the results are
+// bit-identical to four separate wave_sum_f64 calls.
+__device__ __forceinline__ int wave_sum4_slot(int lane) {
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1;
+    return 2 * (b0 ^ b2) + (b1 ^ b2);
+}
+
+__device__ __forceinline__ double wave_sum4_f64(const double (&v)[4]) {
+    const int lane = threadIdx.x & 63;
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1;
+    const bool c1 = (b0 ^ b2) != 0, c2 = (b1 ^ b2) != 0;
+    double t2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = c1 ? v[2 + i] : v[i];
+        const double send = c1 ? v[i] : v[2 + i];
+        t2[i] = keep + dpp_f64<0xB1>(send);
+    }
+    const double keep = c2 ? t2[1] : t2[0];
+    const double send = c2 ? t2[0] : t2[1];
+    double t = keep + dpp_f64<0x4E>(send);
+    t += dpp_f64<0x141>(t);                       // 7 - l within 8
+    t += dpp_f64<0x140>(t);                       // 15 - l within 16
+    {                                             // lane ^ 16 (ds_swizzle, bit mode: and 0x1F, xor 0x10)
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(t), 0x401F);
+        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(t), 0x401F);
+        t += __hiloint2double(hi, lo);
+    }
+    t += __shfl_xor(t, 32, 64);                   // lane ^ 32
+    return t;
+}
+
 }  // namespace slamk

@@ -56,6 +56,11 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     slam_ctx* ctx = new (std::nothrow) slam_ctx();
     if (!ctx) return SLAM_ENOMEM;
     ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* g = getenv("SLAM_AMD_SCORE_WORKGROUPS")) {  // tuning aid: workgroups of the large-H scoring kernel
+        const int v = atoi(g);
+        if (v > 0) ctx->num_cus = v;
+    }
     auto fail = [&](const char* what, hipError_t err) {
         snprintf(g_create_err, sizeof g_create_err, "%s: %s", what, hipGetErrorString(err));
         slam_destroy(ctx);  // releases the streams and pinned buffers created so far
@@ -125,6 +130,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     for (int l = 0; l < SLAM_LANES; ++l) {
         if (ctx->lane_F[l].p) (void)hipFree(ctx->lane_F[l].p);
         if (ctx->select_parts[l].p) (void)hipFree(ctx->select_parts[l].p);
+        if (ctx->score_parts[l].p) (void)hipFree(ctx->score_parts[l].p);
         if (ctx->lane_counts[l].p) (void)hipFree(ctx->lane_counts[l].p);
         if (ctx->lane_errsums[l].p) (void)hipFree(ctx->lane_errsums[l].p);
         if (l > 0 && ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
@@ -423,17 +429,53 @@ static int launch_fused(slam_ctx* ctx, const double2* p0, const double2* p1, int
 }
 
 // large H: a lane per hypothesis for the solve, then the scoring kernel
+// The scoring kernel keeps one chunk of matches in LDS per workgroup (one workgroup per CU) and gives every wave
+// hypotheses of its own.  With several chunks (N > 512 * matches-per-lane) it writes per-chunk partial results, which
+// a small kernel folds in chunk order; the partial tables are bounded by scoring the hypotheses in tiles.
+#define SLAM_SCORE_HG 4       // hypotheses a wave scores at a time
+#define SLAM_SCORE_WAVES 16   // waves per scoring workgroup
+#define SLAM_PARTIAL_BYTES ((size_t)96 << 20)  // upper bound of the per-chunk partial tables of one tile
+
 template <int SAMPLER, bool SAMPSON>
 static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
                         int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
+    const int ppl = N <= 512 ? 1 : (N <= 2048 ? 4 : 8);  // the same limits as SLAM_DISPATCH_SHAPE
+    const int chunk = 512 * ppl;
+    const int nchunks = (N + chunk - 1) / chunk;
+    int lane = 0;  // calls in flight on different internal streams must not share the partial tables
+    for (int l = 1; l < SLAM_LANES; ++l)
+        if (ctx->cur == ctx->lane_stream[l]) lane = l;
+    int tile = H;
+    if (nchunks > 1) {
+        const size_t per_h = (size_t)nchunks * (sizeof(double) + sizeof(int32_t));
+        tile = (int)std::min<size_t>((size_t)H, std::max<size_t>(SLAM_SCORE_HG, SLAM_PARTIAL_BYTES / per_h / SLAM_SCORE_HG * SLAM_SCORE_HG));
+        SLAM_TRY(slam_reserve(ctx, ctx->score_parts[lane], (size_t)tile * per_h + 256));
+    }
     SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SAMPLER>, dim3((H + 63) / 64), dim3(64), 0, p0, p1, N, d_idx, seed, it0,
                          H, (const uint32_t*)ctx->raw.p, ctx->raw_it0, F, (int32_t*)ctx->flags.p));
-    const dim3 grid((H + SLAM_HB - 1) / SLAM_HB);
-#define SLAM_CALL(PPL, WAVES)                                                                                        \
-    return slam_launch(ctx, SLAM_K_SCORE, k_score<SLAM_HB, PPL, WAVES, SAMPSON>, grid, dim3(64 * WAVES), 0, p0, p1, N,         \
-                       (const double*)F, H, thr, counts, errsums)
-    SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
+    for (int t0 = 0; t0 < H; t0 += tile) {
+        const int Ht = std::min(tile, H - t0);
+        const int ngroups = (Ht + SLAM_SCORE_HG - 1) / SLAM_SCORE_HG;
+        const int want_slots = (ngroups + SLAM_SCORE_WAVES - 1) / SLAM_SCORE_WAVES;
+        const int nslots = std::max(1, std::min(ctx->num_cus / std::max(1, std::min(nchunks, ctx->num_cus)), want_slots));
+        const dim3 grid((unsigned)std::min<int64_t>((int64_t)nchunks * nslots, ctx->num_cus));
+        double* pe = errsums + t0;
+        int32_t* pc = counts + t0;
+        if (nchunks > 1) {
+            pe = (double*)ctx->score_parts[lane].p;
+            pc = (int32_t*)((char*)ctx->score_parts[lane].p + (size_t)nchunks * Ht * sizeof(double));
+        }
+#define SLAM_CALL(PPL, WAVES)                                                                                          \
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SCORE, k_score_lds<SLAM_SCORE_HG, PPL, SLAM_SCORE_WAVES, SAMPSON>, grid,          \
+                         dim3(64 * SLAM_SCORE_WAVES), 0, p0, p1, N, (const double*)(F + (size_t)t0 * 9), Ht, thr, nchunks,   \
+                         nslots, pc, pe))
+        SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
+        if (nchunks > 1)
+            SLAM_TRY(slam_launch(ctx, -1, k_combine_chunks, dim3((Ht + 255) / 256), dim3(256), 0, (const int32_t*)pc,
+                                 (const double*)pe, nchunks, Ht, counts + t0, errsums + t0));
+    }
+    return SLAM_OK;
 }
 
 #define SLAM_FUSED_MAX_H 4096

@@ -67,6 +67,52 @@ __global__ void k_full(double a, double b, int iters, long long* out, double* si
     if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
+// The same with operands whose bits keep changing: x <- c - x*x (the logistic map in its chaotic regime, one FMA per
+// step) on eight chains per lane with different starts.  Power, and with it the clock the chip sustains, depends on
+// how many bits toggle: this is the rate real data can reach, the constant-operand loop above is the ceiling.
+__global__ void k_full_chaotic(double c, int iters, long long* out, double* sink) {
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.1 + 1e-3 * (threadIdx.x + 1) + 0.013 * i + 1e-5 * blockIdx.x;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = fma(-x[i], x[i], c);
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+    if (s == 12345.678) sink[0] = s;
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+void full_chip_chaotic(double* d_sink, int threads) {
+    const int blocks = 512 * 1024 / threads, iters = 20000;
+    long long* d_out;
+    hipMalloc(&d_out, blocks * 2 * sizeof(long long));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_full_chaotic, dim3(blocks), dim3(threads), 0, 0, 1.9, iters, d_out, d_sink);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_full_chaotic, dim3(blocks), dim3(threads), 0, 0, 1.9, iters, d_out, d_sink);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(blocks * 2);
+    hipMemcpy(h.data(), d_out, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double mhz_lo = 1e9, mhz_hi = 0;
+    for (int b = 0; b < blocks; ++b) {
+        const double mhz = (double)h[2 * b] / (double)h[2 * b + 1] * 100.0;
+        mhz_lo = mhz < mhz_lo ? mhz : mhz_lo; mhz_hi = mhz > mhz_hi ? mhz : mhz_hi;
+    }
+    const double flop = 2.0 * 64.0 * iters * blocks * (double)threads;
+    printf("full chip, chaotic operands: %d workgroups x %d waves, %.2f ms, %.1f TFLOP/s, shader clock %.0f..%.0f MHz while it ran\n",
+           blocks, threads / 64, ms, flop / (ms * 1e-3) / 1e12, mhz_lo, mhz_hi);
+}
+
 void full_chip(double* d_sink) {
     const int blocks = 512, iters = 20000;
     long long* d_out;
@@ -100,6 +146,9 @@ int main() {
         run<4>(waves, d_cycles, d_sink);
         run<8>(waves, d_cycles, d_sink);
     }
+    full_chip(d_sink);
+    full_chip_chaotic(d_sink, 1024);
+    full_chip_chaotic(d_sink, 512);
     full_chip(d_sink);
     return 0;
 }

@@ -49,3 +49,11 @@ print(f"  workgroup total median {np.median(tot):.0f}  max {tot.max():.0f}; firs
 sel = full[4095 * 8:4095 * 8 + 6].astype(np.float64)
 print("selection kernel (one workgroup), cycles: " + ", ".join(f"{n} {d:.0f}" for n, d in zip(
     ["loads+scan", "wave reduction", "barrier", "fold of 16", "F load + mask"], np.diff(sel))) + f"; total {sel[5] - sel[0]:.0f}")
+
+# per-wave stamps of the score phase (rows 1024 + workgroup * 8 + wave): 0 loop entry, 1 loop end, 2 past the barrier, 3 folded
+w = full[1024 * 8:(1024 + 8 * min(nb, 256)) * 8].reshape(-1, 8, 8).astype(np.float64)     # [workgroup][wave][slot]
+if w[:, :, 0].min() > 0:
+    ref = w[:, :, 0].min(axis=1, keepdims=True)
+    for name, col in (("score loop entry after the first wave's", 0), ("score loop end", 1), ("past the barrier", 2), ("folded", 3)):
+        med = np.median(w[:, :, col] - ref, axis=0)
+        print(f"  per wave, {name}: " + " ".join(f"{x:6.0f}" for x in med))

@@ -239,14 +239,23 @@ def main():
             ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None,
                                             _lib.SAMPLER_COUNTER, 3, 0, HL, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(),
                                             d_mask.data_ptr(), None, None, None))
-        big_step()
+        def settle(fn, seconds=0.25):
+            """Run fn back to back for a while: the clocks the chip holds under a kernel's load take tens of
+            milliseconds to settle (a cold 20-call measurement of this kernel reads 10 % slower)."""
+            t_s = time.perf_counter()
+            while time.perf_counter() - t_s < seconds:
+                for _ in range(20):
+                    fn()
+                ctx.check(lib.slam_synchronize(ctx.handle))
+
+        settle(big_step)
         barrier()
         ctx.check(lib.slam_profile_enable(ctx.handle, 1))
         ctx.check(lib.slam_profile_reset(ctx.handle))
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(50):
             big_step()
-        bdt = (stop_clock() - t0) / 20
+        bdt = (stop_clock() - t0) / 50
         ms, n = C.c_double(0), C.c_int64(0)
         ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms), C.byref(n)))
         ctx.check(lib.slam_profile_enable(ctx.handle, 0))
@@ -259,7 +268,7 @@ def main():
                                            "avg_launch_us": sc_us}}
         # the same 65536 hypotheses scored with the Sampson distance (optional mode, not the reference's residual)
         ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_SAMPSON))
-        big_step()
+        settle(big_step, 0.1)
         barrier()
         ctx.check(lib.slam_profile_enable(ctx.handle, 1))
         ctx.check(lib.slam_profile_reset(ctx.handle))

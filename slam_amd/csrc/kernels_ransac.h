@@ -632,8 +632,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_score_lds(const double2* __restr
                                                           double* __restrict__ out_errsums) {
     constexpr int CH = 64 * SLAM_SLICES * PPL, THREADS = 64 * WAVES;
     static_assert(CH % THREADS == 0 || THREADS % CH == 0, "staging loop");
-    __shared__ double2 s_p0[CH];
-    __shared__ double2 s_p1[CH];
+    // LDS image of the chunk, in the order the loop reads it: [slice w][turn k][image 0 / image 1][lane position], so
+    // that one base address per slice serves all 2 * PPL reads of a slice through immediate offsets
+    __shared__ double2 s_m[SLAM_SLICES][PPL][2][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long full_exec = __ballot(true);
@@ -650,10 +651,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_score_lds(const double2* __restr
         const int slot = u - chunk * nslots;
         const int base = chunk * CH;
         if (u != (int)blockIdx.x) __syncthreads();  // everybody has finished with the previous chunk
-        for (int q = tid; q < CH; q += THREADS) {
+        for (int q = tid; q < CH; q += THREADS) {  // local index q = k * 512 + w * 64 + l
             const int i = min(base + q, N - 1);
-            s_p0[q] = p0[i];
-            s_p1[q] = p1[i];
+            const int k = q / (64 * SLAM_SLICES), w = (q / 64) % SLAM_SLICES, l = q % 64;
+            s_m[w][k][0][l] = p0[i];
+            s_m[w][k][1][l] = p1[i];
         }
         __syncthreads();
         const int nlive = __builtin_amdgcn_readfirstlane(min(N - base, CH));  // real matches of this chunk
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_score_lds(const double2* __restr
 #pragma unroll
                     for (int kk = 0; kk < KB; ++kk) {
                         const int first = (k0 + kk) * 64 * SLAM_SLICES + w * 64;  // local index of lane position 0
-                        const double2 a = s_p0[first + lane], b = s_p1[first + lane];
+                        const double2 a = s_m[w][k0 + kk][0][lane], b = s_m[w][k0 + kk][1][lane];
                         live[kk] = low_lanes_mask(nlive - first);  // lanes whose match exists
 #pragma unroll
                         for (int h = 0; h < HG; ++h)

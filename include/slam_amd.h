@@ -152,6 +152,29 @@ int slam_ransac_f_adaptive(slam_ctx* ctx, const double* p0, const double* p1, in
  * all-gather of a hypothesis-sharded run.  Writes the winning record to out and returns its position. */
 int slam_merge_records(const double* records, int n_records, double* out);
 
+/* ---- exchange step of sharded runs (no counterpart in the reference, which is a single process) ---------------- */
+/* The reference's selection rule (src/epipolar.py:78-81) is what these apply ACROSS ranks; the collectives are RCCL
+ * calls on the context's stream, so a rank's kernels, the exchange and whatever follows stay queued on the device
+ * without a host round trip.  RCCL is loaded at run time (librccl.so.1; SLAM_AMD_RCCL names another file): a process
+ * that never calls these never loads it.
+ * Communicator: either the context's own - rank 0 calls slam_comm_unique_id, hands the 128 bytes to the other ranks
+ * by any means (a file, MPI, torch.distributed), every rank calls slam_comm_init_rank - or any RCCL communicator of
+ * the caller's whose device is the context's, passed as rccl_comm (NULL selects the context's own). */
+#define SLAM_COMM_ID_BYTES 128
+int slam_comm_unique_id(slam_ctx* ctx, void* id128);
+int slam_comm_init_rank(slam_ctx* ctx, const void* id128, int n_ranks, int rank); /* collective; destroyed with the context */
+/* Hypothesis-sharded RANSAC: every rank passes the record its own range produced (device memory, SLAM_REC_LEN
+ * doubles, e.g. d_record of slam_ransac_f_dev); after the call every rank's d_record holds the global winner:
+ * all-gather of the records, then the rule above (more inliers, smaller inlier-error sum, earlier iteration) applied
+ * by a kernel.  Asynchronous on the context's stream. */
+int slam_exchange_winner_dev(slam_ctx* ctx, void* rccl_comm, double* d_record);
+/* Point-sharded pose recovery: sums the four in-front counts of slam_pose_candidates_dev over the ranks in place
+ * (int64[4], device memory), between that call and slam_pose_select_dev.  Asynchronous on the context's stream. */
+int slam_allreduce_counts4_dev(slam_ctx* ctx, void* rccl_comm, int64_t* d_counts4);
+/* slam_merge_records on records in device memory (n_records x SLAM_REC_LEN), asynchronous on the context's stream:
+ * the merge step alone, for callers that gather the records by other means. */
+int slam_merge_records_dev(slam_ctx* ctx, const double* d_records, int n_records, double* d_out);
+
 /* ---- caller-side glue of custom_slam.py --------------------------------------------------------- */
 /* custom_slam.py:85-93 normalize_points: out (N,2), T 3x3 (with the reference's s where 1/s is expected) */
 int slam_normalize_points(slam_ctx* ctx, const double* p, int N, double* out, double* T);

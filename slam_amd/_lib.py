@@ -47,6 +47,11 @@ SIGNATURES = {
     "slam_job_destroy": (None, [_vp]),
     "slam_ransac_f_adaptive": (_int, [_vp, _vp, _vp, _int, _int, _u64, _i64, _int, _f64, _f64, _vp, _vp, _vp]),
     "slam_merge_records": (_int, [_vp, _int, _vp]),
+    "slam_comm_unique_id": (_int, [_vp, _vp]),
+    "slam_comm_init_rank": (_int, [_vp, _vp, _int, _int]),
+    "slam_exchange_winner_dev": (_int, [_vp, _vp, _vp]),
+    "slam_allreduce_counts4_dev": (_int, [_vp, _vp, _vp]),
+    "slam_merge_records_dev": (_int, [_vp, _vp, _int, _vp]),
     "slam_normalize_points": (_int, [_vp, _vp, _int, _vp, _vp]),
     "slam_fundamental_to_essential": (_int, [_vp, _vp, _vp, _vp]),
     "slam_triangulate": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),

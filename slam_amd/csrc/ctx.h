@@ -73,6 +73,10 @@ struct slam_ctx {
     char* h_stage = nullptr;
     size_t h_stage_cap = 0;
 
+    void* comm = nullptr;               // the context's own RCCL communicator (slam_comm_init_rank), or none
+    int comm_ranks = 0;
+    slam_buf xchg;                      // gathered winner records of the exchange step
+
     unsigned char* noalloc_scratch = nullptr;  // this device's address of the code object's scratch array
 
     bool profiling = false;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include "exchange.h"
 #include "kernels_ransac.h"
 #include "kernels_tri.h"
 #include "kernels_track.h"
@@ -123,6 +124,9 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)slam_sync_all(ctx);  // a context that failed half-way through slam_create has no stream yet
+    if (ctx->comm && slamx::rccl().ok) (void)slamx::rccl().CommDestroy((slamx::ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    if (ctx->xchg.p) (void)hipFree(ctx->xchg.p);
     slam_buf* bufs[] = {&ctx->pts, &ctx->norm, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
                         &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track, &ctx->match, &ctx->batch};
     for (slam_buf* b : bufs)
@@ -841,6 +845,82 @@ extern "C" int slam_merge_records(const double* records, int n_records, double* 
     }
     memcpy(out, records + (size_t)best * SLAM_REC_LEN, SLAM_REC_LEN * sizeof(double));
     return best;
+}
+
+// ================================================================================================
+// exchange step of the sharded runs (RCCL)
+// ================================================================================================
+extern "C" int slam_merge_records_dev(slam_ctx* ctx, const double* d_records, int n_records, double* d_out) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, d_records && d_out && n_records >= 1, "NULL pointer or no records");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->cur = ctx->stream;
+    return slam_launch(ctx, -1, slamx::k_merge_records, dim3(1), dim3(64), 0, d_records, n_records, d_out);
+}
+
+extern "C" int slam_comm_unique_id(slam_ctx* ctx, void* id128) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, id128 != nullptr, "NULL pointer");
+    SLAM_TRY(slam_need_rccl(ctx));
+    static_assert(sizeof(slamx::ncclUniqueId) == SLAM_COMM_ID_BYTES, "unique id size");
+    SLAM_RCCL(ctx, slamx::rccl().GetUniqueId((slamx::ncclUniqueId*)id128));
+    return SLAM_OK;
+}
+
+extern "C" int slam_comm_init_rank(slam_ctx* ctx, const void* id128, int n_ranks, int rank) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, id128 != nullptr, "NULL pointer");
+    SLAM_REQUIRE(ctx, n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank outside 0..n_ranks-1");
+    SLAM_REQUIRE(ctx, ctx->comm == nullptr, "the context already has a communicator");
+    SLAM_TRY(slam_need_rccl(ctx));
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    SLAM_TRY(slam_reserve(ctx, ctx->xchg, (size_t)n_ranks * SLAM_REC_LEN * sizeof(double)));
+    slamx::ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    slamx::ncclComm_t comm = nullptr;
+    SLAM_RCCL(ctx, slamx::rccl().CommInitRank(&comm, n_ranks, id, rank));
+    ctx->comm = comm;
+    ctx->comm_ranks = n_ranks;
+    return SLAM_OK;
+}
+
+// communicator and its size for an exchange call: the caller's (any RCCL communicator whose device is the context's),
+// or the context's own
+static int exchange_comm(slam_ctx* ctx, void* rccl_comm, slamx::ncclComm_t* comm, int* n_ranks) {
+    SLAM_TRY(slam_need_rccl(ctx));
+    if (rccl_comm) {
+        *comm = (slamx::ncclComm_t)rccl_comm;
+        SLAM_RCCL(ctx, slamx::rccl().CommCount(*comm, n_ranks));
+    } else {
+        SLAM_REQUIRE(ctx, ctx->comm != nullptr, "no communicator: call slam_comm_init_rank first or pass one");
+        *comm = (slamx::ncclComm_t)ctx->comm;
+        *n_ranks = ctx->comm_ranks;
+    }
+    return SLAM_OK;
+}
+
+extern "C" int slam_exchange_winner_dev(slam_ctx* ctx, void* rccl_comm, double* d_record) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, d_record != nullptr, "NULL pointer");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    slamx::ncclComm_t comm;
+    int n_ranks = 0;
+    SLAM_TRY(exchange_comm(ctx, rccl_comm, &comm, &n_ranks));
+    SLAM_TRY(slam_reserve(ctx, ctx->xchg, (size_t)n_ranks * SLAM_REC_LEN * sizeof(double)));  // grows for a caller's communicator only
+    SLAM_RCCL(ctx, slamx::rccl().AllGather(d_record, ctx->xchg.p, SLAM_REC_LEN, slamx::kNcclFloat64, comm, ctx->stream));
+    ctx->cur = ctx->stream;
+    return slam_launch(ctx, -1, slamx::k_merge_records, dim3(1), dim3(64), 0, (const double*)ctx->xchg.p, n_ranks, d_record);
+}
+
+extern "C" int slam_allreduce_counts4_dev(slam_ctx* ctx, void* rccl_comm, int64_t* d_counts4) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, d_counts4 != nullptr, "NULL pointer");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    slamx::ncclComm_t comm;
+    int n_ranks = 0;
+    SLAM_TRY(exchange_comm(ctx, rccl_comm, &comm, &n_ranks));
+    SLAM_RCCL(ctx, slamx::rccl().AllReduce(d_counts4, d_counts4, 4, slamx::kNcclInt64, slamx::kNcclSum, comm, ctx->stream));
+    return SLAM_OK;
 }
 
 // ================================================================================================

@@ -187,3 +187,39 @@ def allgather_winner(local_record, group=None):
     out = torch.empty((world, REC_LEN), dtype=torch.float64, device=t.device)
     dist.all_gather_into_tensor(out, t.reshape(1, REC_LEN).contiguous(), group=group)
     return merge_records(out.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the same exchange inside the library: RCCL collectives on the context's stream, merge on the device
+# ------------------------------------------------------------------------------------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_init(ctx, rank=0, world=1, group=None):
+    """Give the context its own RCCL communicator over `world` ranks (collective: every rank calls it).  Rank 0 draws
+    the identifier; with more than one rank it travels through a torch.distributed broadcast in `group` (any backend;
+    a C host would hand the 128 bytes over by whatever means it has)."""
+    import ctypes as C
+    buf = (C.c_char * COMM_ID_BYTES)()
+    if rank == 0:
+        ctx.check(ctx.lib.slam_comm_unique_id(ctx.handle, C.addressof(buf)))
+    if world > 1:
+        import torch.distributed as dist
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        buf.raw = box[0]
+    ctx.check(ctx.lib.slam_comm_init_rank(ctx.handle, C.addressof(buf), int(world), int(rank)))
+
+
+def exchange_winner_dev(ctx, d_record, comm=None):
+    """Hypothesis-sharded run: d_record (device address of this rank's 12-double winner record) holds the global
+    winner on every rank afterwards.  All-gather plus the selection rule (src/epipolar.py:78-81) on the device, queued
+    on the context's stream: nothing returns to the host.  comm: a caller's RCCL communicator, or None for the
+    context's own (comm_init)."""
+    ctx.check(ctx.lib.slam_exchange_winner_dev(ctx.handle, comm, d_record))
+
+
+def allreduce_counts4_dev(ctx, d_counts4, comm=None):
+    """Point-sharded pose recovery: sums the four in-front counts (int64[4] on the device) over the ranks in place,
+    between slam_pose_candidates_dev and slam_pose_select_dev, on the context's stream."""
+    ctx.check(ctx.lib.slam_allreduce_counts4_dev(ctx.handle, comm, d_counts4))

@@ -254,7 +254,7 @@ int slam_track_pose_dev(slam_ctx* ctx, const double* previous_pose, const double
 /* Descriptors are packed 256-bit strings, 32 bytes each (what ORB emits; the reference unpacks them to one byte
  * per bit before matching, custom_slam.py:51, which changes nothing in the distances).  At most 2^22 train
  * descriptors.
- * custom_slam.py:14-26 match_knn_brute_force with num_matches = k (1 or 2): index, distance are (n0, k) int32, nearest
+ * custom_slam.py:14-26 match_knn_brute_force with num_matches = k (1 to 8): index, distance are (n0, k) int32, nearest
  * first, equal distances in ascending train index (the reference's stable sort); -1 where n1 < k. */
 int slam_match_knn(slam_ctx* ctx, const uint8_t* des0, int n0, const uint8_t* des1, int n1, int k, int32_t* index,
                    int32_t* distance);

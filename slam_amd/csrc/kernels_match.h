@@ -123,4 +123,89 @@ __global__ __launch_bounds__(1024) void k_match_finish(const uint2* __restrict__
     if (tid == 0) *n_matched = s_base;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The K nearest for any K up to SLAM_MATCH_MAX_K (custom_slam.py:24 slices the sorted list at any num_matches; the
+// pipeline itself asks for two).  Same layout as the 2-NN pair above - a query per lane, a wave-uniform train
+// descriptor through scalar loads, one 32-bit key per candidate - with the running best kept as a sorted register
+// array: a new key sinks through it with one min and one max per position.
+// part[(slice * n0 + q) * K + j]; out index / distance are (n0, k) with k <= K, -1 where fewer than k train
+// descriptors exist.
+// ------------------------------------------------------------------------------------------------
+#define SLAM_MATCH_MAX_K 8
+
+template <int K>
+__device__ __forceinline__ void topk_insert(uint32_t key, uint32_t (&best)[K]) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t lo = min(best[j], key);
+        key = max(best[j], key);
+        best[j] = lo;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_match_knnk(const uint32_t* __restrict__ des0, const uint32_t* __restrict__ des1,
+                                                    int n0, int n1, int per_slice, uint32_t* __restrict__ part) {
+    __shared__ uint32_t s_k[4][K][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 64 + lane;
+    const int qq = q < n0 ? q : n0 - 1;
+    uint32_t a[8];
+    {
+        const uint4 lo = *reinterpret_cast<const uint4*>(des0 + (size_t)qq * 8);
+        const uint4 hi = *reinterpret_cast<const uint4*>(des0 + (size_t)qq * 8 + 4);
+        a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w;
+        a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+    }
+    const int s_lo = blockIdx.y * per_slice;
+    const int s_hi = min(n1, s_lo + per_slice);
+    const int quarter = (per_slice + 3) >> 2;
+    const int j_lo = min(s_hi, s_lo + wave * quarter);
+    const int j_hi = min(s_hi, j_lo + quarter);
+    uint32_t best[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = SLAM_MATCH_EMPTY;
+#pragma unroll 2
+    for (int j = j_lo; j < j_hi; ++j) {
+        const uint32_t* __restrict__ t = des1 + (size_t)j * 8;  // uniform address: scalar loads
+        uint32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) d += __popc(a[w] ^ t[w]);
+        topk_insert<K>((d << SLAM_MATCH_INDEX_BITS) | (uint32_t)j, best);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) s_k[wave][j][lane] = best[j];
+    __syncthreads();
+    if (wave == 0 && q < n0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+#pragma unroll
+            for (int j = 0; j < K; ++j) topk_insert<K>(s_k[w][j][lane], best);
+#pragma unroll
+        for (int j = 0; j < K; ++j) part[((size_t)blockIdx.y * n0 + q) * K + j] = best[j];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_match_finish_k(const uint32_t* __restrict__ part, int slices, int n0, int k,
+                                                        int32_t* __restrict__ index, int32_t* __restrict__ distance) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n0) return;
+    uint32_t best[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = SLAM_MATCH_EMPTY;
+    for (int s = 0; s < slices; ++s)
+#pragma unroll
+        for (int j = 0; j < K; ++j) topk_insert<K>(part[((size_t)s * n0 + q) * K + j], best);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < k) {
+            const bool none = best[j] == SLAM_MATCH_EMPTY;
+            index[(size_t)q * k + j] = none ? -1 : (int)(best[j] & (SLAM_MATCH_MAX_TRAIN - 1));
+            distance[(size_t)q * k + j] = none ? -1 : (int)(best[j] >> SLAM_MATCH_INDEX_BITS);
+        }
+    }
+}
+
 }  // namespace slamk

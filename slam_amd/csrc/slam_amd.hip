@@ -1590,12 +1590,45 @@ extern "C" int slam_match_points(slam_ctx* ctx, const uint8_t* des0, const doubl
     return match_host(ctx, des0, pts0, n0, des1, pts1, n1, matched0, matched1, n_matched, index, distance);
 }
 
+// k nearest for 3 <= k <= SLAM_MATCH_MAX_K: sorted register arrays of four or eight keys
+template <int K>
+static int match_knnk_host(slam_ctx* ctx, const uint8_t* des0, int n0, const uint8_t* des1, int n1, int k, int32_t* index,
+                           int32_t* distance) {
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const int slices = match_slices(n0, n1);
+    const int per_slice = (n1 + slices - 1) / slices;
+    const size_t b_part = align256((size_t)n0 * slices * K * sizeof(uint32_t));
+    const size_t b_d0 = align256((size_t)n0 * 32), b_d1 = align256((size_t)n1 * 32);
+    const size_t b_i = align256((size_t)n0 * k * sizeof(int32_t));
+    SLAM_TRY(slam_reserve(ctx, ctx->match, b_part + b_d0 + b_d1 + 2 * b_i));
+    char* at = (char*)ctx->match.p;
+    auto take = [&](size_t bytes) { char* p = at; at += bytes; return p; };
+    uint32_t* d_part = (uint32_t*)take(b_part);
+    uint8_t* d_d0 = (uint8_t*)take(b_d0);
+    uint8_t* d_d1 = (uint8_t*)take(b_d1);
+    int32_t* d_index = (int32_t*)take(b_i);
+    int32_t* d_distance = (int32_t*)take(b_i);
+    SLAM_HIP(ctx, hipMemcpyAsync(d_d0, des0, (size_t)n0 * 32, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(d_d1, des1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
+    ctx->cur = ctx->stream;
+    SLAM_TRY(slam_launch(ctx, SLAM_K_MATCH, k_match_knnk<K>, dim3((n0 + 63) / 64, slices), dim3(256), 0,
+                         (const uint32_t*)d_d0, (const uint32_t*)d_d1, n0, n1, per_slice, d_part));
+    SLAM_TRY(slam_launch(ctx, -1, k_match_finish_k<K>, dim3((n0 + 255) / 256), dim3(256), 0, (const uint32_t*)d_part, slices,
+                         n0, k, d_index, d_distance));
+    SLAM_HIP(ctx, hipMemcpyAsync(index, d_index, (size_t)n0 * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipMemcpyAsync(distance, d_distance, (size_t)n0 * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
 extern "C" int slam_match_knn(slam_ctx* ctx, const uint8_t* des0, int n0, const uint8_t* des1, int n1, int k,
                               int32_t* index, int32_t* distance) {
     if (!ctx) return SLAM_EINVAL;
     SLAM_REQUIRE(ctx, des0 && des1 && index && distance, "NULL pointer");
-    SLAM_REQUIRE(ctx, k == 1 || k == 2, "k must be 1 or 2");
+    SLAM_REQUIRE(ctx, k >= 1 && k <= SLAM_MATCH_MAX_K, "k must be between 1 and 8");
     SLAM_MATCH_ARGS_OK(ctx, n0, n1);
+    if (k > 4) return match_knnk_host<8>(ctx, des0, n0, des1, n1, k, index, distance);
+    if (k > 2) return match_knnk_host<4>(ctx, des0, n0, des1, n1, k, index, distance);
     if (k == 2) return match_host(ctx, des0, nullptr, n0, des1, nullptr, n1, nullptr, nullptr, nullptr, index, distance);
     std::vector<int32_t> i2((size_t)n0 * 2), d2((size_t)n0 * 2);
     SLAM_TRY(match_host(ctx, des0, nullptr, n0, des1, nullptr, n1, nullptr, nullptr, nullptr, i2.data(), d2.data()));

@@ -10,6 +10,8 @@ import numpy as np
 from . import _lib
 from ._lib import f64, ptr
 
+MAX_K = 8   # SLAM_MATCH_MAX_K
+
 
 def pack_descriptors(des):
     des = np.asarray(des)
@@ -22,7 +24,7 @@ def pack_descriptors(des):
 
 def knn(img0_descriptors, img1_descriptors, num_matches=2, ctx=None):
     """(index, distance), each (n0, num_matches) int32, nearest first; equal distances in ascending image-1 index."""
-    assert num_matches in (1, 2), "the GPU matcher keeps the one or two nearest descriptors"
+    assert 1 <= num_matches <= MAX_K, "the GPU matcher keeps up to eight nearest descriptors"
     d0, d1 = pack_descriptors(img0_descriptors), pack_descriptors(img1_descriptors)
     index = np.empty((len(d0), num_matches), dtype=np.int32)
     distance = np.empty((len(d0), num_matches), dtype=np.int32)

@@ -31,6 +31,28 @@ def random_descriptors(n0, n1, n_true, flips, seed):
     return d0, d1
 
 
+def test_knn_three_and_more_nearest(ctx):
+    """match_knn_brute_force slices its sorted list at any num_matches (custom_slam.py:24): the reference's own output
+    for num_matches = 3, then 3..8 nearest on random descriptors with many equal distances against the oracle, and a
+    train set smaller than num_matches (the reference's rows are then shorter)."""
+    g = load_golden("matching")
+    index, distance = matching.knn(g["k3_des0"], g["k3_des1"], 3, ctx)
+    assert np.array_equal(index, g["k3_knn_index"]) and np.array_equal(distance, g["k3_knn_distance"])
+    rng = np.random.default_rng(8)
+    for k in range(3, matching.MAX_K + 1):
+        n0, n1 = int(rng.integers(1, 700)), int(rng.integers(k, 900))
+        few = rng.integers(0, 256, (12, 32), dtype=np.uint8)
+        d0 = few[rng.integers(0, 12, n0)] ^ (rng.integers(0, 256, (n0, 32), dtype=np.uint8) & 1)
+        d1 = few[rng.integers(0, 12, n1)] ^ (rng.integers(0, 256, (n1, 32), dtype=np.uint8) & 1)
+        wi, wd = so.match_knn_brute_force(d0, d1, k)
+        gi, gd = matching.knn(d0, d1, k, ctx)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd), k
+    out = matching.match_knn_brute_force(g["k3_des0"], g["k3_des1"][:2], 5, ctx)
+    assert all(len(row) == 2 for row in out)
+    with pytest.raises(AssertionError):
+        matching.knn(g["k3_des0"], g["k3_des1"], 9, ctx)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_knn_matches_golden(ctx, name):
     g = load_golden("matching")

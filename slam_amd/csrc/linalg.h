@@ -228,56 +228,12 @@ __device__ __forceinline__ void jacobi_svd(double (&A)[M][N], double (&V)[N][N],
     jacobi_sweeps<M, N, false>(A, V, max_sweeps, 1e-15);
 }
 
-// Unit null vector of the 8 x 9 system  sum_r n[r] * A[r][c] = 0  for c = 0..7, where A (9 x 8) holds the
-// design matrix transposed (row = monomial, column = correspondence).  Householder QR of A; the null vector is
-// the last column of Q = H0 H1 ... H7.  Orthogonal transforms only, so the result is backward stable like an SVD's.
-__device__ __forceinline__ void null_vector_9x8(double (&A)[9][8], double (&n)[9]) {
-    double beta[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double sigma = 0.0;
-#pragma unroll
-        for (int r = j + 1; r < 9; ++r) sigma = fma(A[r][j], A[r][j], sigma);
-        const double x0 = A[j][j];
-        const double s2 = fma(x0, x0, sigma);
-        const double normx = (s2 > 0.0) ? s2 * rsqrt(s2) : 0.0;
-        const double alpha = (x0 >= 0.0) ? -normx : normx;
-        const double v0 = x0 - alpha;                    // same sign as x0: no cancellation
-        const double vtv = fma(v0, v0, sigma);
-        // beta only has to match v to rounding for H = I - beta v v^T to be orthogonal; zero column: H = I
-        const double bj = (vtv > 0.0) ? 2.0 * fast_rcp(vtv) : 0.0;
-        beta[j] = bj;
-        A[j][j] = v0;
-#pragma unroll
-        for (int c = j + 1; c < 8; ++c) {
-            double s = v0 * A[j][c];
-#pragma unroll
-            for (int r = j + 1; r < 9; ++r) s = fma(A[r][j], A[r][c], s);
-            s *= bj;
-            A[j][c] = fma(-s, v0, A[j][c]);
-#pragma unroll
-            for (int r = j + 1; r < 9; ++r) A[r][c] = fma(-s, A[r][j], A[r][c]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 9; ++r) n[r] = (r == 8) ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 7; j >= 0; --j) {
-        double s = A[j][j] * n[j];
-#pragma unroll
-        for (int r = j + 1; r < 9; ++r) s = fma(A[r][j], n[r], s);
-        s *= beta[j];
-        n[j] = fma(-s, A[j][j], n[j]);
-#pragma unroll
-        for (int r = j + 1; r < 9; ++r) n[r] = fma(-s, A[r][j], n[r]);
-    }
+// Cross-lane helpers of the cooperative solve (eight lanes per system, eight systems per wave; all 64 lanes active).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
 }
 
-// The same null vector computed by EIGHT lanes per system (eight systems per wave): lane c of a group of eight
-// consecutive lanes holds column c of the 9 x 8 matrix (a[r] = A[r][c]).  Every scalar operation of
-// null_vector_9x8 happens exactly once per column and in the same order, only on the lane that owns the column
-// (the reflector of step j on lane j, its application to column c on lane c), so the result is bit-identical; the
-// reflector travels to the other lanes of its group through ds_swizzle.  All 64 lanes must be active.
 template <int J>
 __device__ __forceinline__ double bcast8(double x) {  // x of lane J of each group of eight lanes
     constexpr int pattern = (J << 5) | 0x18;          // bit mode: lane' = (lane & 0b11000) | J
@@ -286,71 +242,81 @@ __device__ __forceinline__ double bcast8(double x) {  // x of lane J of each gro
     return __hiloint2double(hi, lo);
 }
 
-template <int J>
-__device__ __forceinline__ void null9x8_forward_step(double (&a)[9], int c, double& beta_own) {
-    // every lane forms the reflector of ITS column at row J; only lane J's is used
-    double sigma = 0.0;
+__device__ __forceinline__ double bperm_f64(int byte_addr, double x) {  // x of lane byte_addr / 4
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ uint32_t group8_max_u32(uint32_t k) {  // maximum over the eight lanes of a group, on all of them
+    k = max(k, dpp_u32<0xB1>(k));   // lane ^ 1
+    k = max(k, dpp_u32<0x4E>(k));   // lane ^ 2
+    k = max(k, dpp_u32<0x141>(k));  // 7 - l within 8
+    return k;
+}
+
+// Null vector of the 8 x 9 design matrix by EIGHT lanes per system: lane i of a group of eight consecutive lanes holds
+// row i (a[0..8], a[8] = 1).  Gauss-Jordan elimination with row pivoting over the columns 8, 0, 1, ..., 6; column 7 is
+// the free one, so the result is n with n[7] = 1 (NOT normalised; the projection that follows normalises).
+//   * Column 8 is all ones: row 0 is its pivot and every multiplier is 1 (rows 1..7 become differences).
+//   * Column c: the pivot is the unused row with the largest |a[c]|, compared on the high word of the double with its
+//     three lowest bits replaced by 7 - row (a pivot within 2^-17 of the largest serves as well, and the keys of the
+//     unused rows are distinct, so exactly one lane is the pivot); the maximum travels by three DPP exchanges.
+//     The pivot row and the reciprocal of its entry reach the group through ds_bpermute; every row but the pivot -
+//     rows used earlier included, which is what makes the last step a read-out instead of a back substitution -
+//     subtracts its multiple.
+//   * After the eight steps row i holds its pivot entry and a[7] only: n[column of row i] = -a[7] / pivot.
+// Elementwise arithmetic only (no sums across lanes), backward error of the order of the rounding unit times the
+// condition number, like the SVD the reference calls (measured on 10^4 samples: at most 1.4 eps cond).
+// A zero pivot (rank-deficient sample) leaves its column out (multiplier 0, n = 0 there): finite garbage where the
+// reference returns an arbitrary null vector.
+template <int C>
+__device__ __forceinline__ void null8x9_step(double (&a)[9], int i, int group_addr, bool& used, double& rsave, int& addr_out) {
+    const double x = a[C];
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const uint32_t key = used ? 0u : ((hi & 0x7ffffff8u) | (uint32_t)(7 - i) | 0x80000000u);
+    const uint32_t mk = group8_max_u32(key);
+    const bool is_p = key == mk;
+    const int addr = group_addr | (int)((7u - (mk & 7u)) << 2);
+    const double rinv_own = (x != 0.0) ? fast_rcp(x) : 0.0;
+    const double rinv = bperm_f64(addr, rinv_own);
+    double piv[8];
 #pragma unroll
-    for (int r = J + 1; r < 9; ++r) sigma = fma(a[r], a[r], sigma);
-    const double x0 = a[J];
-    const double s2 = fma(x0, x0, sigma);
-    const double normx = (s2 > 0.0) ? s2 * rsqrt(s2) : 0.0;
-    const double alpha = (x0 >= 0.0) ? -normx : normx;
-    const double v0 = x0 - alpha;
-    const double vtv = fma(v0, v0, sigma);
-    const double bj = (vtv > 0.0) ? 2.0 * fast_rcp(vtv) : 0.0;
-    if (c == J) { a[J] = v0; beta_own = bj; }
-    const double rv0 = bcast8<J>(v0), rb = bcast8<J>(bj);
-    double tail[9];
+    for (int j = C + 1; j < 8; ++j) piv[j] = bperm_f64(addr, a[j]);
+    const double f = is_p ? 0.0 : x * rinv;
 #pragma unroll
-    for (int r = J + 1; r < 9; ++r) tail[r] = bcast8<J>(a[r]);
-    if (c > J) {
-        double s = rv0 * a[J];
+    for (int j = C + 1; j < 8; ++j) a[j] = fma(-f, piv[j], a[j]);
+    rsave = is_p ? rinv_own : rsave;
+    used = used || is_p;
+    addr_out = addr;
+}
+
+__device__ __forceinline__ void null_vector_8x9_by_eight_lanes(double (&a)[9], double (&n)[9]) {
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int i = lane & 7, group_addr = (lane & ~7) << 2;
+    {
+        double piv[8];
 #pragma unroll
-        for (int r = J + 1; r < 9; ++r) s = fma(tail[r], a[r], s);
-        s *= rb;
-        a[J] = fma(-s, rv0, a[J]);
+        for (int j = 0; j < 8; ++j) piv[j] = bcast8<0>(a[j]);
+        const double f = (i == 0) ? 0.0 : 1.0;
 #pragma unroll
-        for (int r = J + 1; r < 9; ++r) a[r] = fma(-s, tail[r], a[r]);
+        for (int j = 0; j < 8; ++j) a[j] = fma(-f, piv[j], a[j]);
     }
-}
-
-template <int J>
-__device__ __forceinline__ void null9x8_backward_step(const double (&a)[9], double beta_own, double (&n)[9]) {
-    const double rv0 = bcast8<J>(a[J]), rb = bcast8<J>(beta_own);
-    double tail[9];
+    bool used = (i == 0);
+    double rsave = 1.0;
+    int addr[7];
+    null8x9_step<0>(a, i, group_addr, used, rsave, addr[0]);
+    null8x9_step<1>(a, i, group_addr, used, rsave, addr[1]);
+    null8x9_step<2>(a, i, group_addr, used, rsave, addr[2]);
+    null8x9_step<3>(a, i, group_addr, used, rsave, addr[3]);
+    null8x9_step<4>(a, i, group_addr, used, rsave, addr[4]);
+    null8x9_step<5>(a, i, group_addr, used, rsave, addr[5]);
+    null8x9_step<6>(a, i, group_addr, used, rsave, addr[6]);
+    const double xo = -a[7] * rsave;
 #pragma unroll
-    for (int r = J + 1; r < 9; ++r) tail[r] = bcast8<J>(a[r]);
-    double s = rv0 * n[J];
-#pragma unroll
-    for (int r = J + 1; r < 9; ++r) s = fma(tail[r], n[r], s);
-    s *= rb;
-    n[J] = fma(-s, rv0, n[J]);
-#pragma unroll
-    for (int r = J + 1; r < 9; ++r) n[r] = fma(-s, tail[r], n[r]);
-}
-
-// a: this lane's column (destroyed); c = lane & 7; n: the null vector, the same on the eight lanes of a group
-__device__ __forceinline__ void null_vector_9x8_by_eight_lanes(double (&a)[9], int c, double (&n)[9]) {
-    double beta_own = 0.0;
-    null9x8_forward_step<0>(a, c, beta_own);
-    null9x8_forward_step<1>(a, c, beta_own);
-    null9x8_forward_step<2>(a, c, beta_own);
-    null9x8_forward_step<3>(a, c, beta_own);
-    null9x8_forward_step<4>(a, c, beta_own);
-    null9x8_forward_step<5>(a, c, beta_own);
-    null9x8_forward_step<6>(a, c, beta_own);
-    null9x8_forward_step<7>(a, c, beta_own);
-#pragma unroll
-    for (int r = 0; r < 9; ++r) n[r] = (r == 8) ? 1.0 : 0.0;
-    null9x8_backward_step<7>(a, beta_own, n);
-    null9x8_backward_step<6>(a, beta_own, n);
-    null9x8_backward_step<5>(a, beta_own, n);
-    null9x8_backward_step<4>(a, beta_own, n);
-    null9x8_backward_step<3>(a, beta_own, n);
-    null9x8_backward_step<2>(a, beta_own, n);
-    null9x8_backward_step<1>(a, beta_own, n);
-    null9x8_backward_step<0>(a, beta_own, n);
+    for (int c = 0; c < 7; ++c) n[c] = bperm_f64(addr[c], xo);
+    n[7] = 1.0;
+    n[8] = bcast8<0>(xo);
 }
 
 // Closest rank-2 matrix (Frobenius) of f / ||f||_F :  U diag(s0, s1, 0) V^T.
@@ -363,7 +329,7 @@ __device__ __forceinline__ void null_vector_9x8_by_eight_lanes(double (&a)[9], i
 //   adj(M - lambda I) = (l1 - lambda)(l2 - lambda) v3 v3^T, so its largest column is parallel to v3.
 // The estimate only has to be good to a few digits: the sweeps that follow work on f itself and restore full
 // accuracy (they do not see the squared condition number of M).
-__device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&F)[9]) {
+__device__ __forceinline__ void rank2_project_sweeps(const double (&f_in)[9], double (&F)[9]) {
     double nrm2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) nrm2 = fma(f_in[i], f_in[i], nrm2);
@@ -450,6 +416,94 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
             for (int j = 0; j < 3; ++j) s = fma(w[j] * B[r][j], V[c][j], s);
             F[3 * r + c] = s;
         }
+}
+
+// The same projection on the short path every well-separated matrix takes: with v the least right singular vector,
+//   U diag(s0, s1, 0) V^T = f - (f v) v^T,
+// so v alone is needed, to full accuracy.  Start as above (least root of the characteristic cubic, largest column of the
+// adjugate), complete v to an orthonormal basis with a Householder reflector (w = v + sign(v_2) e_2, beta = 1 / (1 +
+// |v_2|): no cancellation, no case distinction), then ONE joint first-order step on f itself makes f v orthogonal to
+// the images of the two other basis vectors: with b_j = f h_j, b_2 = f v, a_j = |b_j|^2, c_ij = b_i . b_j,
+//   t0 (a0 - a2) + t1 c01 = c02,   t0 c01 + t1 (a1 - a2) = c12,   v <- v - t0 h0 - t1 h1,   b_2 <- b_2 - t0 b_0 - t1 b_1.
+// The step leaves an error of order t^2, so it is final when |t0|, |t1| <= 1e-8; a wave in which some lane's start was
+// worse than that (least and middle singular values close together, or no usable start) takes the sweeping version.
+__device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&F)[9]) {
+    double nrm2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nrm2 = fma(f_in[i], f_in[i], nrm2);
+    const double inv = rsqrt(nrm2);
+    double f[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[r][c] = f_in[3 * r + c] * inv;
+    const double m00 = fma(f[0][0], f[0][0], fma(f[1][0], f[1][0], f[2][0] * f[2][0]));
+    const double m01 = fma(f[0][0], f[0][1], fma(f[1][0], f[1][1], f[2][0] * f[2][1]));
+    const double m02 = fma(f[0][0], f[0][2], fma(f[1][0], f[1][2], f[2][0] * f[2][2]));
+    const double m11 = fma(f[0][1], f[0][1], fma(f[1][1], f[1][1], f[2][1] * f[2][1]));
+    const double m12 = fma(f[0][1], f[0][2], fma(f[1][1], f[1][2], f[2][1] * f[2][2]));
+    const double m22 = fma(f[0][2], f[0][2], fma(f[1][2], f[1][2], f[2][2] * f[2][2]));
+    const double c2 = m00 + m11 + m22;
+    const double k12 = fma(m11, m22, -m12 * m12), k02 = fma(m01, m22, -m12 * m02), k01 = fma(m01, m12, -m11 * m02);
+    const double c1 = fma(m00, m11, -m01 * m01) + fma(m00, m22, -m02 * m02) + k12;
+    const double c0 = fma(m00, k12, fma(-m01, k02, m02 * k01));
+    double lam = 0.0;
+#pragma unroll
+    for (int it = 0; it < SLAM_CUBIC_NEWTON_STEPS; ++it) {
+        const double p = fma(fma(c2 - lam, lam, -c1), lam, c0);
+        const double dp = fma(fma(-3.0, lam, c2 + c2), lam, -c1);
+        lam = fma(-p, __builtin_amdgcn_rcp(dp), lam);  // an approximate reciprocal is enough: the iteration self-corrects
+    }
+    const double a00 = m00 - lam, a11 = m11 - lam, a22 = m22 - lam;
+    const double g00 = fma(a11, a22, -m12 * m12), g11 = fma(a00, a22, -m02 * m02), g22 = fma(a00, a11, -m01 * m01);
+    const double g01 = fma(m02, m12, -m01 * a22), g02 = fma(m01, m12, -m02 * a11), g12 = fma(m01, m02, -a00 * m12);
+    const bool k0 = (g00 >= g11) && (g00 >= g22);
+    const bool k1 = !k0 && (g11 >= g22);
+    double v0 = k0 ? g00 : (k1 ? g01 : g02);
+    double v1 = k0 ? g01 : (k1 ? g11 : g12);
+    double v2 = k0 ? g02 : (k1 ? g12 : g22);
+    const double vn2 = fma(v0, v0, fma(v1, v1, v2 * v2));
+    const bool usable = (vn2 > 0.0) && (vn2 < 1e300);  // false for NaN, zero or overflow
+    const double vi = rsqrt(vn2);
+    v0 *= vi; v1 *= vi; v2 *= vi;
+    // h0, h1: the first two columns of I - beta w w^T
+    const double w2 = v2 + (v2 >= 0.0 ? 1.0 : -1.0);
+    const double beta = fast_rcp(1.0 + fabs(v2));
+    const double bw0 = beta * v0, bw1 = beta * v1;
+    const double h00 = fma(-bw0, v0, 1.0), h01 = -bw0 * v1, h02 = -bw0 * w2;  // h0 = (h00, h01, h02)
+    const double h10 = h01, h11 = fma(-bw1, v1, 1.0), h12 = -bw1 * w2;        // h1 = (h10, h11, h12)
+    double b0[3], b1[3], b2[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        b0[r] = fma(f[r][0], h00, fma(f[r][1], h01, f[r][2] * h02));
+        b1[r] = fma(f[r][0], h10, fma(f[r][1], h11, f[r][2] * h12));
+        b2[r] = fma(f[r][0], v0, fma(f[r][1], v1, f[r][2] * v2));
+    }
+    const double q0 = fma(b0[0], b0[0], fma(b0[1], b0[1], b0[2] * b0[2]));
+    const double q1 = fma(b1[0], b1[0], fma(b1[1], b1[1], b1[2] * b1[2]));
+    const double q2 = fma(b2[0], b2[0], fma(b2[1], b2[1], b2[2] * b2[2]));
+    const double c01 = fma(b0[0], b1[0], fma(b0[1], b1[1], b0[2] * b1[2]));
+    const double c02 = fma(b0[0], b2[0], fma(b0[1], b2[1], b0[2] * b2[2]));
+    const double c12 = fma(b1[0], b2[0], fma(b1[1], b2[1], b1[2] * b2[2]));
+    const double d0 = q0 - q2, d1 = q1 - q2;
+    const double det = fma(d0, d1, -c01 * c01);
+    const double idet = fast_rcp(det);
+    const double t0 = fma(c02, d1, -c12 * c01) * idet, t1 = fma(c12, d0, -c02 * c01) * idet;
+    const bool fine = usable && (det > 0.0) && (fabs(t0) <= 1e-8) && (fabs(t1) <= 1e-8);
+    if (__any(!fine)) {  // wave-uniform
+        rank2_project_sweeps(f_in, F);
+        return;
+    }
+    const double u0 = fma(-t1, h10, fma(-t0, h00, v0));
+    const double u1 = fma(-t1, h11, fma(-t0, h01, v1));
+    const double u2 = fma(-t1, h12, fma(-t0, h02, v2));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double br = fma(-t1, b1[r], fma(-t0, b0[r], b2[r]));
+        F[3 * r + 0] = fma(-br, u0, f[r][0]);
+        F[3 * r + 1] = fma(-br, u1, f[r][1]);
+        F[3 * r + 2] = fma(-br, u2, f[r][2]);
+    }
 }
 
 // Right singular vector of the smallest singular value of a 4 x 4 matrix A (held as A[row][col]; destroyed).

@@ -46,6 +46,10 @@ for i, nme in enumerate(names):
     print(f"  {nme:8s} median {q[0]:9.0f}  90% {q[1]:9.0f}  99% {q[2]:9.0f}  max {d[:, i].max():9.0f}")
 tot = st[:, -1] - st[:, 0]
 print(f"  workgroup total median {np.median(tot):.0f}  max {tot.max():.0f}; first start to last end {st[:, -1].max() - t0:.0f} cycles")
+starts = np.sort(st[:, 0] - t0)
+ends = np.sort(st[:, -1] - t0)
+print("  workgroup starts after the first one, cycles: " + " ".join(f"{q:.0f}" for q in np.quantile(starts, [0.1, 0.5, 0.9, 1.0]))
+      + "; ends: " + " ".join(f"{q:.0f}" for q in np.quantile(ends, [0.0, 0.1, 0.5, 0.9, 1.0])))
 sel = full[4095 * 8:4095 * 8 + 6].astype(np.float64)
 print("selection kernel (one workgroup), cycles: " + ", ".join(f"{n} {d:.0f}" for n, d in zip(
     ["loads+scan", "wave reduction", "barrier", "fold of 16", "F load + mask"], np.diff(sel))) + f"; total {sel[5] - sel[0]:.0f}")
@@ -57,3 +61,12 @@ if w[:, :, 0].min() > 0:
     for name, col in (("score loop entry after the first wave's", 0), ("score loop end", 1), ("past the barrier", 2), ("folded", 3)):
         med = np.median(w[:, :, col] - ref, axis=0)
         print(f"  per wave, {name}: " + " ".join(f"{x:6.0f}" for x in med))
+
+# constant-clock stamps (build with STAMP_FLAGS=-DSLAM_WALL_STAMPS): when the workgroups of the last launch started and ended
+wl = full[3072 * 8:(3072 + min(nb, 256)) * 8].reshape(-1, 8)[:, :2].astype(np.float64)
+if wl.min() > 0:
+    t0w = wl[:, 0].min()
+    s_ns, e_ns = np.sort(wl[:, 0] - t0w) * 10.0, np.sort(wl[:, 1] - t0w) * 10.0
+    print("constant clock, ns after the first workgroup's start: starts " + " ".join(f"{q:.0f}" for q in np.quantile(s_ns, [0.1, 0.5, 0.9, 1.0]))
+          + "; ends " + " ".join(f"{q:.0f}" for q in np.quantile(e_ns, [0.0, 0.1, 0.5, 0.9, 1.0]))
+          + f"; lifetime median {np.median(wl[:, 1] - wl[:, 0]) * 10:.0f} ns = {np.median(tot):.0f} shader cycles")

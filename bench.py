@@ -178,6 +178,7 @@ def main():
 
     timed = [jobs[i % LANES] for i in range(args.steps)]
     bt = timed_bursts(timed)
+    print("burst us/step:", " ".join(f"{x / args.steps * 1e6:.2f}" for x in bt), file=sys.stderr)
     dt = float(np.median(bt))
     rec = d_rec.cpu().numpy()
     assert all(torch.equal(r, recs[0]) for r in recs), "lanes disagree"

@@ -52,7 +52,7 @@ struct slam_ctx {
     slam_buf mask;      // N u8
     slam_buf record;    // SLAM_REC_LEN f64 + flags
     slam_buf raw;       // MT19937 words [raw_n][SLAM_RAW_WORDS]
-    slam_buf X4;        // 4 candidate planes of N*3 f64
+    slam_buf X4;        // 2 candidate planes of N*3 f64 (candidates 0 and 2; 1 and 3 are their negatives)
     slam_buf X;         // N*3 f64 staging
     slam_buf small;     // small matrices: candidates, poses, T, E ...
     slam_buf flags;     // int32[4] error flags written by kernels

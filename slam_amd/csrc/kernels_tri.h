@@ -92,7 +92,7 @@ struct PairArgs {
     double* errsums;              // H       }
     double* record;               // SLAM_REC_LEN
     unsigned long long* counts4;  // 4
-    double* X4;                   // 4 x N x 3
+    double* X4;                   // 2 x N x 3
     double* X;                    // N x 3
     uint8_t* good;                // N
     double* pose;                 // 16
@@ -115,45 +115,68 @@ __global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* _
 
 // K4b: the four (R,t) candidates of one E   (reference: src/epipolar.py:113-127)
 //   in front of camera 1: X_z > 0 ; in front of camera 2: (X - t) . (R e_z) > 0 ; count points passing both.
-// Every candidate's points go to its own plane X4[c][N][3]; counts4 (int64) must be zero on entry.
-__global__ __launch_bounds__(256) void k_triangulate4(const double* __restrict__ pw, const double2* __restrict__ p0,
-                                                      const double2* __restrict__ p1, int64_t N,
-                                                      double* __restrict__ X4,
-                                                      unsigned long long* __restrict__ counts4,
-                                                      const PairArgs* __restrict__ batch) {
-    __shared__ int s_cnt[4][4];
+// The points go to two planes X4[r][N][3], r = 0, 1: plane r holds candidate 2 r, and candidate 2 r + 1 is its negative.
+// counts4 (int64) must be zero on entry.
+// A workgroup is ONE wave and takes 256 consecutive matches, 64 at a time.  The Jacobi polish makes waves finish a
+// match at different times; as four-wave workgroups the early waves' slots stayed empty until the last wave had
+// ended (2.6 of 4 waves per SIMD on average).  The wave adds its four counts with one atomic instruction.
+#define SLAM_TRI4_PER_WG 256
+#ifndef SLAM_TRI4_WAVES_PER_SIMD
+#define SLAM_TRI4_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(const double* __restrict__ pw, const double2* __restrict__ p0,
+                                                     const double2* __restrict__ p1, int64_t N, double* __restrict__ X4,
+                                                     unsigned long long* __restrict__ counts4,
+                                                     const PairArgs* __restrict__ batch) {
     if (batch) {
         const PairArgs& a = batch[blockIdx.y];
         pw = a.pw; p0 = a.r0; p1 = a.r1; N = a.N; X4 = a.X4; counts4 = a.counts4;
-        if ((int64_t)blockIdx.x * 256 >= N) return;  // the grid is sized for the largest pair
+        if ((int64_t)blockIdx.x * SLAM_TRI4_PER_WG >= N) return;  // the grid is sized for the largest pair
     }
-    const int tid = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-    const bool live = i < N;
-    const int64_t ii = live ? i : N - 1;
-    const double2 a = p0[ii], b = p1[ii];
+    const int lane = threadIdx.x;
+    // The cameras and the cheirality vectors of the four candidates are staged in LDS once: read from there they are
+    // broadcast reads that wait for LDS traffic only.  Read from global memory inside the candidate loop they were vector
+    // loads whose wait also covered the previous candidate's point stores (44 % of the wave cycles were such waits).
+    __shared__ double s_pw[PW_E];
+    for (int q = lane; q < PW_E; q += 64) s_pw[q] = pw[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int cnt[4] = {0, 0, 0, 0};  // wave-uniform
 #pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-        const double* __restrict__ cand = pw + PW_CAND + c * PW_CAND_LEN;
-        double X[3];
-        triangulate_one(pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
-        const double tx = cand[PW_CAND_T], ty = cand[PW_CAND_T + 1], tz = cand[PW_CAND_T + 2];
-        const double cx = cand[PW_CAND_CZ], cy = cand[PW_CAND_CZ + 1], cz = cand[PW_CAND_CZ + 2];
-        const bool f1 = X[2] > 0.0;
-        const bool f2 = ((X[0] - tx) * cx + (X[1] - ty) * cy + (X[2] - tz) * cz) > 0.0;
-        const int n = __popcll(__ballot(live && f1 && f2));
-        if ((tid & 63) == 0) s_cnt[c][tid >> 6] = n;
-        if (live) {
-            double* o = X4 + ((size_t)c * (size_t)N + (size_t)i) * 3;
-            o[0] = X[0];
-            o[1] = X[1];
-            o[2] = X[2];
+    for (int k = 0; k < SLAM_TRI4_PER_WG / 64; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * SLAM_TRI4_PER_WG + k * 64 + lane;
+        if ((int64_t)blockIdx.x * SLAM_TRI4_PER_WG + k * 64 >= N) break;  // uniform
+        const bool live = i < N;
+        const double2 a = p0[live ? i : N - 1], b = p1[live ? i : N - 1];
+        // Candidates 2 r and 2 r + 1 share the rotation and have opposite translations (pose_prepare): the last column
+        // of the second camera changes sign and nothing else does, the first camera's last column is zero, so the whole
+        // last column of D changes sign, the least singular vector changes the sign of its last component, and the
+        // point of candidate 2 r + 1 is exactly the negative of candidate 2 r's (IEEE arithmetic is symmetric under a
+        // change of sign).  Two triangulations serve the four candidates; (X' - t') . c = -((X - t) . c) likewise.
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            asm volatile("" ::: "memory");  // the LDS reads stay inside the loop: hoisted, they cost 40 registers
+            const double* cand = s_pw + PW_CAND + 2 * r * PW_CAND_LEN;
+            double X[3];
+            triangulate_one(s_pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
+            const double tx = cand[PW_CAND_T], ty = cand[PW_CAND_T + 1], tz = cand[PW_CAND_T + 2];
+            const double cx = cand[PW_CAND_CZ], cy = cand[PW_CAND_CZ + 1], cz = cand[PW_CAND_CZ + 2];
+            const double s2 = (X[0] - tx) * cx + (X[1] - ty) * cy + (X[2] - tz) * cz;
+            const int n_pos = __popcll(__ballot(live && X[2] > 0.0 && s2 > 0.0));
+            const int n_neg = __popcll(__ballot(live && -X[2] > 0.0 && -s2 > 0.0));
+            cnt[0] += r == 0 ? n_pos : 0; cnt[1] += r == 0 ? n_neg : 0;
+            cnt[2] += r == 1 ? n_pos : 0; cnt[3] += r == 1 ? n_neg : 0;
+            if (live) {  // plane r holds candidate 2 r; candidate 2 r + 1 is its negative (candidate_point below)
+                double* o = X4 + ((size_t)r * (size_t)N + (size_t)i) * 3;
+                o[0] = X[0];
+                o[1] = X[1];
+                o[2] = X[2];
+            }
         }
     }
-    __syncthreads();
-    if (tid < 4) {
-        const int n = s_cnt[tid][0] + s_cnt[tid][1] + s_cnt[tid][2] + s_cnt[tid][3];
-        if (n) atomicAdd(&counts4[tid], (unsigned long long)n);
+    if (lane < 4) {
+        const int n = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
+        if (n) atomicAdd(&counts4[lane], (unsigned long long)n);
     }
 }
 
@@ -335,10 +358,11 @@ __global__ __launch_bounds__(64) void k_pose_select(const double* __restrict__ p
 // copy the winner's plane to the output and optionally flag X_z > 0 (custom_slam.py:114)
 __global__ __launch_bounds__(256) void k_emit_points(const double* __restrict__ X4, const int32_t* __restrict__ winner,
                                                      int64_t N, double* __restrict__ X, uint8_t* __restrict__ good) {
-    const double* src = X4 + (size_t)(*winner) * (size_t)N * 3;
+    const int w = *winner;
+    const double* src = X4 + (size_t)(w >> 1) * (size_t)N * 3;  // two planes: candidate 2 r + 1 is the negative of 2 r
     const int64_t total = N * 3;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const double v = src[e];
+        const double v = (w & 1) ? -src[e] : src[e];
         X[e] = v;
         if (good && (e % 3) == 2) good[e / 3] = v > 0.0 ? 1 : 0;
     }
@@ -446,10 +470,10 @@ __global__ __launch_bounds__(256) void k_select_emit(const double* __restrict__ 
         if (threadIdx.x == 0) *winner = w;
         if (threadIdx.x < 16) pose[threadIdx.x] = pw[PW_CAND + w * PW_CAND_LEN + PW_CAND_POSE + threadIdx.x];
     }
-    const double* src = X4 + (size_t)w * (size_t)N * 3;
+    const double* src = X4 + (size_t)(w >> 1) * (size_t)N * 3;  // two planes: candidate 2 r + 1 is the negative of 2 r
     const int64_t total = N * 3;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const double v = src[e];
+        const double v = (w & 1) ? -src[e] : src[e];
         X[e] = v;
         if (good && (e % 3) == 2) good[e / 3] = v > 0.0 ? 1 : 0;
     }

@@ -1024,8 +1024,8 @@ extern "C" int slam_triangulate(slam_ctx* ctx, const double* P0, const double* P
 // pose recovery
 // ================================================================================================
 static int tri4_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int64_t N, unsigned long long* d_counts4) {
-    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
-    return slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)2 * (size_t)N * 3 * sizeof(double)));
+    return slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + SLAM_TRI4_PER_WG - 1) / SLAM_TRI4_PER_WG)), dim3(64), 0,
                        (const double*)ctx->small.p, (const double2*)d_p0, (const double2*)d_p1, N, (double*)ctx->X4.p,
                        d_counts4, (const PairArgs*)nullptr);
 }
@@ -1037,7 +1037,7 @@ extern "C" int slam_pose_candidates_dev(slam_ctx* ctx, const double* E_host, con
     SLAM_REQUIRE(ctx, N >= 1 && N < ((int64_t)1 << 31) * 256, "N out of range");
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
     double* pw = (double*)ctx->small.p;
-    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)2 * (size_t)N * 3 * sizeof(double)));
     Mat3x2 ek;
     memcpy(ek.A, E_host, sizeof ek.A);
     memcpy(ek.B, K_host, sizeof ek.B);
@@ -1049,7 +1049,7 @@ extern "C" int slam_pose_select_dev(slam_ctx* ctx, const int64_t* d_counts4, int
                                     int32_t* d_winner) {
     if (!ctx) return SLAM_EINVAL;
     SLAM_REQUIRE(ctx, d_counts4 && d_pose && d_winner, "NULL pointer");
-    SLAM_REQUIRE(ctx, N >= 1 && ctx->X4.cap >= (size_t)4 * (size_t)N * 3 * sizeof(double),
+    SLAM_REQUIRE(ctx, N >= 1 && ctx->X4.cap >= (size_t)2 * (size_t)N * 3 * sizeof(double),
                  "slam_pose_candidates_dev must run first with the same N");
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
     SLAM_TRY(slam_launch(ctx, -1, k_pose_select, dim3(1), dim3(64), 0, (const double*)ctx->small.p,
@@ -1114,7 +1114,7 @@ static int init_pair_on_device(slam_ctx* ctx, const double* r0, const double* r1
     double *n0 = (double*)ctx->norm.p, *n1 = (double*)((char*)ctx->norm.p + stride);
     SLAM_TRY(slam_reserve(ctx, ctx->X, (size_t)N * 3 * sizeof(double)));
     SLAM_TRY(slam_reserve(ctx, ctx->mask, (size_t)N));
-    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)4 * (size_t)N * 3 * sizeof(double)));
+    SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)2 * (size_t)N * 3 * sizeof(double)));
     SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)H * 9 * sizeof(double)));
     SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t)));
     SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
@@ -1206,12 +1206,12 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
     const size_t b_blk = align256((size_t)P * PB_LEN * sizeof(double));
     const size_t b_F = align256((size_t)P * maxH * 9 * sizeof(double)), b_c = align256((size_t)P * maxH * sizeof(int32_t));
     const size_t b_e = align256((size_t)P * maxH * sizeof(double)), b_args = align256((size_t)P * sizeof(PairArgs));
-    SLAM_TRY(slam_reserve(ctx, ctx->batch, 4 * b_pts + 5 * b_x + b_m + b_blk + b_F + b_c + b_e + 3 * b_args));
+    SLAM_TRY(slam_reserve(ctx, ctx->batch, 4 * b_pts + 3 * b_x + b_m + b_blk + b_F + b_c + b_e + 3 * b_args));
     SLAM_TRY(slam_fill_raw_table(ctx, SLAM_SEED_BASE, 0, maxH));
     char* at = (char*)ctx->batch.p;
     auto take = [&](size_t bytes) { char* q = at; at += bytes; return q; };
     double *r0 = (double*)take(b_pts), *r1 = (double*)take(b_pts), *n0 = (double*)take(b_pts), *n1 = (double*)take(b_pts);
-    double* X4 = (double*)take(4 * b_x);
+    double* X4 = (double*)take(2 * b_x);
     double* dX = (double*)take(b_x);
     uint8_t* dmask = (uint8_t*)take(b_m);
     double* blocks = (double*)take(b_blk);
@@ -1235,7 +1235,7 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
         a.F_all = dF + (size_t)p * maxH * 9; a.counts = dC + (size_t)p * maxH; a.errsums = dE + (size_t)p * maxH;
         a.record = blk + PB_REC;
         a.counts4 = (unsigned long long*)(blk + PB_COUNTS);
-        a.X4 = X4 + 4 * 3 * off; a.X = dX + 3 * off; a.good = dmask + off;
+        a.X4 = X4 + 2 * 3 * off; a.X = dX + 3 * off; a.good = dmask + off;
         a.pose = blk + PB_POSE; a.winner = (int32_t*)(blk + PB_WIN);
     }
     int class_begin[4] = {0, 0, 0, 0};
@@ -1285,7 +1285,7 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
                          (const double2*)nullptr, (const double2*)nullptr, 0, rcut, (double*)nullptr, (uint8_t*)nullptr, all));
     SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1, P), dim3(64), 0, kk, (const double*)nullptr, (double*)nullptr,
                          (unsigned long long*)nullptr, all));
-    SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((maxN + 255) / 256), P), dim3(256), 0,
+    SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((maxN + SLAM_TRI4_PER_WG - 1) / SLAM_TRI4_PER_WG), P), dim3(64), 0,
                          (const double*)nullptr, (const double2*)nullptr, (const double2*)nullptr, (int64_t)0,
                          (double*)nullptr, (unsigned long long*)nullptr, all));
     const unsigned eb = (unsigned)std::min<int64_t>(((int64_t)maxN * 3 + 255) / 256, 64);

@@ -1,9 +1,10 @@
 """Bulk triangulation (four candidates per point) on device-resident points: kernel time per launch."""
 import argparse
 import ctypes as C
+import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 

@@ -383,73 +383,60 @@ __device__ __forceinline__ void solve8_by_eight_lanes(const double2 a, const dou
     rank2_project(f, F);
 }
 
-// K1 standalone (single solves, and large H before k_score_lds): one wave per workgroup draws the index sets of its
-// eight hypotheses one after the other with all 64 lanes (the draw of the fused kernel; the eight rows of random
-// words are requested together up front), then solves them, eight lanes each.
+// The same solve by one lane (throughput form: 64 hypotheses per wave); bit-identical to solve8_by_eight_lanes.
+__device__ __forceinline__ void solve_from_indices(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
+                                                   const int32_t (&sel)[8], double (&F)[9]) {
+    double A[8][9];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = min(max(sel[r], 0), N - 1);  // never read outside the arrays, whatever idx holds
+        const double2 a = p0[i], b = p1[i];
+        A[r][0] = b.x * a.x; A[r][1] = b.x * a.y; A[r][2] = b.x;
+        A[r][3] = b.y * a.x; A[r][4] = b.y * a.y; A[r][5] = b.y;
+        A[r][6] = a.x;       A[r][7] = a.y;       A[r][8] = 1.0;
+    }
+    double f[9];
+    null_vector_8x9_one_lane(A, f);
+    rank2_project(f, F);
+}
+
+// draw (or read) the 8 indices of iteration it0 + h.  SAMPLER: -1 = given in idx_in, else SLAM_SAMPLER_*.
+// words/pool: LDS with `lanes` columns, this lane using column `lane`.
+template <int SAMPLER>
+__device__ __forceinline__ bool indices_for(int h, int N, const int32_t* __restrict__ idx_in, uint64_t seed, int64_t it0,
+                                            const uint32_t* __restrict__ raw, int64_t raw_it0, uint32_t* words,
+                                            uint8_t* pool, int lane, int lanes, int32_t (&sel)[8]) {
+    if (SAMPLER < 0) {
+        const int4 lo = ((const int4*)idx_in)[2 * (size_t)h], hi = ((const int4*)idx_in)[2 * (size_t)h + 1];
+        sel[0] = lo.x; sel[1] = lo.y; sel[2] = lo.z; sel[3] = lo.w;
+        sel[4] = hi.x; sel[5] = hi.y; sel[6] = hi.z; sel[7] = hi.w;
+        return true;
+    } else if (SAMPLER == SLAM_SAMPLER_CPYTHON) {
+        return sample_cpython(raw + (size_t)(it0 + h - raw_it0) * SLAM_RAW_WORDS, N, 8, sel, words, pool, lane, lanes);
+    } else {
+        return sample_counter8(seed, (uint64_t)(it0 + h), N, 8, sel);
+    }
+}
+
+// K1 standalone: one lane per hypothesis.  Used for single solves and for large H, where the number of instructions
+// per hypothesis counts (the eight-lane form of the fused kernel issues five times as many) and 64 hypotheses per
+// wave keep the vector units busy.
 template <int SAMPLER>
 __global__ __launch_bounds__(64) void k_solve(const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
                                               const int32_t* __restrict__ idx_in, uint64_t seed, int64_t it0, int H,
                                               const uint32_t* __restrict__ raw, int64_t raw_it0,
                                               double* __restrict__ Fout, int32_t* __restrict__ flags) {
-    __shared__ int32_t s_sel[8][8];
-    __shared__ int32_t s_scratch[16];
-    __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX : 1];
-    const int lane = (int)threadIdx.x;
-    const int h0 = blockIdx.x * 8;
-    bool ok = true;
-    if constexpr (SAMPLER == SLAM_SAMPLER_COUNTER) {
-        // One Philox evaluation per lane covers the eight hypotheses: lane 8 g + b computes block b of hypothesis g, i.e.
-        // words 4 b .. 4 b + 3 of its stream.  The first 32 words almost always hold eight distinct in-range values
-        // (the draw then equals the sequential walk's); otherwise the walk itself is done.
-        __shared__ uint32_t s_w[8][32];
-        {
-            const int g = lane >> 3, b = lane & 7;
-            const uint64_t it = (uint64_t)(it0 + min(h0 + g, H - 1));  // (surplus groups redo the last hypothesis)
-            uint32_t w[4];
-            philox4x32_10((uint32_t)b, 0u, (uint32_t)it, (uint32_t)(it >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s_w[g][4 * b + u] = w[u];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int g = 0; g < 8; ++g) {
-            const uint32_t word = lane < 32 ? s_w[g][lane] : 0xFFFFFFFFu;  // all ones: out of range for every N <= 2^27
-            if (!select8_from_words(word, N, s_scratch, s_sel[g])) {       // wave-uniform
-                int32_t sel[8];
-                ok &= sample_counter8(seed, (uint64_t)(it0 + min(h0 + g, H - 1)), N, 8, sel);
-                if (lane == 0) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) s_sel[g][q] = sel[q];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next draw reuses the scratch words
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else {
-        uint32_t word[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            word[g] = 0;
-            if (SAMPLER == SLAM_SAMPLER_CPYTHON)  // (surplus groups redo the last hypothesis: the solve needs every lane)
-                word[g] = raw[(size_t)(it0 + min(h0 + g, H - 1) - raw_it0) * SLAM_RAW_WORDS + lane];
-        }
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            ok &= indices_for_wave<SAMPLER>(min(h0 + g, H - 1), N, word[g], idx_in, seed, it0, raw, raw_it0, s_pool, s_scratch, s_sel[g]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next draw reuses the scratch words
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (!ok && lane == 0) atomicOr(&flags[0], 1);
-    const int g = lane >> 3, i = lane & 7;
-    const int mine = min(max(s_sel[g][i], 0), N - 1);  // never read outside the arrays, whatever idx holds
+    __shared__ uint32_t s_words[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_PREFETCH_WORDS * 64 : 1];
+    __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * 64 : 1];
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    int32_t sel[8];
+    const bool ok = indices_for<SAMPLER>(h, N, idx_in, seed, it0, raw, raw_it0, s_words, s_pool, threadIdx.x, 64, sel);
+    if (!ok) atomicOr(&flags[0], 1);
     double F[9];
-    solve8_by_eight_lanes(p0[mine], p1[mine], F);
-    if (i == 0 && h0 + g < H) {
+    solve_from_indices(p0, p1, N, sel, F);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) Fout[(size_t)(h0 + g) * 9 + q] = F[q];
-    }
+    for (int i = 0; i < 9; ++i) Fout[(size_t)h * 9 + i] = F[i];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -319,6 +319,80 @@ __device__ __forceinline__ void null_vector_8x9_by_eight_lanes(double (&a)[9], d
     n[8] = bcast8<0>(xo);
 }
 
+// The same elimination by ONE lane per system (A[r][c], r = 0..7 rows, c = 0..8 columns, A[r][8] = 1): every
+// arithmetic operation of the eight-lane version is done once per row with the same operands, in the same order per
+// matrix entry, and the pivot is chosen by the same integer keys, so the null vector has the same bits.  What the
+// other version does with lane exchanges is done here with selections over the rows (the pivot row is the one-hot
+// sum of the rows).  Throughput form: 64 systems per wave.
+__device__ __forceinline__ void null_vector_8x9_one_lane(double (&A)[8][9], double (&n)[9]) {
+    {
+        double piv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) piv[j] = A[0][j];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const double f = (r == 0) ? 0.0 : 1.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) A[r][j] = fma(-f, piv[j], A[r][j]);
+        }
+    }
+    bool used[8];
+    double rsave[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { used[r] = (r == 0); rsave[r] = 1.0; }
+    int prow[7];
+    auto step = [&](auto CC) {
+        constexpr int C = decltype(CC)::value;
+        uint32_t key[8], mk = 0u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t hi = (uint32_t)__double2hiint(A[r][C]);
+            key[r] = used[r] ? 0u : ((hi & 0x7ffffff8u) | (uint32_t)(7 - r) | 0x80000000u);
+            mk = max(mk, key[r]);
+        }
+        bool isp[8];
+        double xp = 0.0, piv[8];
+#pragma unroll
+        for (int j = C + 1; j < 8; ++j) piv[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            isp[r] = key[r] == mk;
+            xp = isp[r] ? A[r][C] : xp;
+#pragma unroll
+            for (int j = C + 1; j < 8; ++j) piv[j] = isp[r] ? A[r][j] : piv[j];
+        }
+        const double rinv = (xp != 0.0) ? fast_rcp(xp) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const double f = isp[r] ? 0.0 : A[r][C] * rinv;
+#pragma unroll
+            for (int j = C + 1; j < 8; ++j) A[r][j] = fma(-f, piv[j], A[r][j]);
+            rsave[r] = isp[r] ? rinv : rsave[r];
+            used[r] = used[r] || isp[r];
+        }
+        prow[C] = 7 - (int)(mk & 7u);
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    double xo[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xo[r] = -A[r][7] * rsave[r];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        double v = xo[0];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v = (prow[c] == r) ? xo[r] : v;
+        n[c] = v;
+    }
+    n[7] = 1.0;
+    n[8] = xo[0];
+}
+
 // Closest rank-2 matrix (Frobenius) of f / ||f||_F :  U diag(s0, s1, 0) V^T.
 // With B = f V (columns sigma_i u_i) this is the sum over the two largest columns of B_i v_i^T.
 //
@@ -426,7 +500,8 @@ __device__ __forceinline__ void rank2_project_sweeps(const double (&f_in)[9], do
 // the images of the two other basis vectors: with b_j = f h_j, b_2 = f v, a_j = |b_j|^2, c_ij = b_i . b_j,
 //   t0 (a0 - a2) + t1 c01 = c02,   t0 c01 + t1 (a1 - a2) = c12,   v <- v - t0 h0 - t1 h1,   b_2 <- b_2 - t0 b_0 - t1 b_1.
 // The step leaves an error of order t^2, so it is final when |t0|, |t1| <= 1e-8; a wave in which some lane's start was
-// worse than that (least and middle singular values close together, or no usable start) takes the sweeping version.
+// worse than that (least and middle singular values close together, or no usable start) also runs the sweeping
+// version, whose result replaces the short path's on those lanes only.
 __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&F)[9]) {
     double nrm2 = 0.0;
 #pragma unroll
@@ -490,10 +565,9 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
     const double idet = fast_rcp(det);
     const double t0 = fma(c02, d1, -c12 * c01) * idet, t1 = fma(c12, d0, -c02 * c01) * idet;
     const bool fine = usable && (det > 0.0) && (fabs(t0) <= 1e-8) && (fabs(t1) <= 1e-8);
-    if (__any(!fine)) {  // wave-uniform
-        rank2_project_sweeps(f_in, F);
-        return;
-    }
+    double Fs[9];
+    const bool some_not_fine = __any(!fine);  // wave-uniform
+    if (some_not_fine) rank2_project_sweeps(f_in, Fs);
     const double u0 = fma(-t1, h10, fma(-t0, h00, v0));
     const double u1 = fma(-t1, h11, fma(-t0, h01, v1));
     const double u2 = fma(-t1, h12, fma(-t0, h02, v2));
@@ -503,6 +577,11 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
         F[3 * r + 0] = fma(-br, u0, f[r][0]);
         F[3 * r + 1] = fma(-br, u1, f[r][1]);
         F[3 * r + 2] = fma(-br, u2, f[r][2]);
+    }
+    // a lane's result never depends on which other lanes share its wave: fine lanes keep the short path's numbers
+    if (some_not_fine) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = fine ? F[i] : Fs[i];
     }
 }
 

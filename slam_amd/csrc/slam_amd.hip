@@ -455,7 +455,7 @@ static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int
         tile = (int)std::min<size_t>((size_t)H, std::max<size_t>(SLAM_SCORE_HG, SLAM_PARTIAL_BYTES / per_h / SLAM_SCORE_HG * SLAM_SCORE_HG));
         SLAM_TRY(slam_reserve(ctx, ctx->score_parts[lane], (size_t)tile * per_h + 256));
     }
-    SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SAMPLER>, dim3((H + 7) / 8), dim3(64), 0, p0, p1, N, d_idx, seed, it0,
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve<SAMPLER>, dim3((H + 63) / 64), dim3(64), 0, p0, p1, N, d_idx, seed, it0,
                          H, (const uint32_t*)ctx->raw.p, ctx->raw_it0, F, (int32_t*)ctx->flags.p));
     for (int t0 = 0; t0 < H; t0 += tile) {
         const int Ht = std::min(tile, H - t0);

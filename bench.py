@@ -40,7 +40,8 @@ PEAK_HBM = 8000.0               # GB/s
 # the kernels are compute-bound ("mfma" class of the two roofline classes) but issue vector FP64, not MFMA; on this
 # part the two peaks coincide
 BOUND_DETAIL = "FP64 vector ALU issue (no MFMA instructions); MI355X's dense FP64 MFMA peak is the same 78.6 TFLOP/s"
-TRI_FLOP_PER_CAND = 700.0       # executed per (point, candidate): D build/scaling 80, warm start 550, Jacobi check 70
+TRI_FLOP_PER_SOLVE = 700.0      # executed per DLT solve: D build/scaling 80, warm start 550, Jacobi check 70
+TRI_SOLVES_PER_POINT = 2.0      # candidates with opposite translations give exactly opposite points: two solves serve four
 TRI_BYTES_PER_POINT = 88.0      # algorithmic: 2 x 32 B in (count pass + write pass) + 24 B out
 
 
@@ -203,18 +204,18 @@ def main():
     ctx.check(lib.slam_profile_enable(ctx.handle, 0))
     score_us = kern["score"]
     achieved = FLOP_PER_EVAL * N_HYP * N_MATCHES / (score_us * 1e-6) / 1e12
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("k_ransac_bytes_per_launch")
-        except Exception:
-            traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")   # memory-side bytes per launch from rocprofv3 PMC passes
+    try:
+        traffic_file = json.load(open(tpath))
+    except Exception:
+        traffic_file = {}
+    traffic = traffic_file.get("k_ransac_bytes_per_launch")
     roofline = {"kernel": "k_ransac (sample+solve+score)", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": achieved, "peak": PEAK_FP64_VALU,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VALU,
                 "traffic": traffic,
                 "avg_launch_us": score_us, "flop_per_launch": FLOP_PER_EVAL * N_HYP * N_MATCHES,
-                "algorithmic_bytes_per_launch": N_MATCHES * 32 + N_HYP * 72 + N_HYP * 12,
+                # matches in, per hypothesis 64 sampler words in and F, count, error sum out
+                "algorithmic_bytes_per_launch": N_MATCHES * 32 + N_HYP * (256 + 72 + 12),
                 "other_kernels_us": {"k_select": kern["select"]}}
 
     out = {"metric": "RANSAC 8-pt hypotheses scored/sec @N=4096 matches", "value": value, "unit": "hypotheses/s",
@@ -266,6 +267,8 @@ def main():
                               "hypotheses_per_sec": HL / bdt, "residual_evals_per_sec": HL * N_MATCHES / bdt,
                               "roofline": {"kernel": "k_score_lds", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
                                            "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": tfl / PEAK_FP32_VALU,
+                                           "traffic": traffic_file.get("k_score_lds_bytes_per_launch"),
+                                           "algorithmic_bytes_per_launch": N_MATCHES * 32 + HL * 72 + HL * 12,
                                            "avg_launch_us": sc_us}}
         # the same 65536 hypotheses scored with the Sampson distance (optional mode, not the reference's residual)
         ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_SAMPSON))
@@ -389,14 +392,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tdt = float(t.item())
         tri_ms = ms.value / max(n.value, 1)
-        tf = 4 * NT * TRI_FLOP_PER_CAND / (tri_ms * 1e-3) / 1e12
+        tf = TRI_SOLVES_PER_POINT * NT * TRI_FLOP_PER_SOLVE / (tri_ms * 1e-3) / 1e12
         out["aux"] = {"metric": "triangulated pts/sec (4 candidates per point, cheirality selection)",
                       "value": world * NT * tsteps / tdt, "unit": "points/s", "points_per_gpu": NT,
                       "candidate_triangulations_per_sec": 4 * world * NT * tsteps / tdt,
                       "cheirality_counts": d_counts.cpu().tolist(),
                       "roofline": {"kernel": "k_triangulate4", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": tf,
                                    "peak": PEAK_FP64_VALU, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU,
-                                   "avg_launch_ms": tri_ms, "flop_per_candidate": TRI_FLOP_PER_CAND,
+                                   "avg_launch_ms": tri_ms, "flop_per_dlt_solve": TRI_FLOP_PER_SOLVE,
+                                   "dlt_solves_per_point": TRI_SOLVES_PER_POINT,
                                    "hbm_GBps_algorithmic": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9,
                                    "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM}}
         del p0, p1, d_X

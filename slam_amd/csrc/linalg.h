@@ -565,9 +565,6 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
     const double idet = fast_rcp(det);
     const double t0 = fma(c02, d1, -c12 * c01) * idet, t1 = fma(c12, d0, -c02 * c01) * idet;
     const bool fine = usable && (det > 0.0) && (fabs(t0) <= 1e-8) && (fabs(t1) <= 1e-8);
-    double Fs[9];
-    const bool some_not_fine = __any(!fine);  // wave-uniform
-    if (some_not_fine) rank2_project_sweeps(f_in, Fs);
     const double u0 = fma(-t1, h10, fma(-t0, h00, v0));
     const double u1 = fma(-t1, h11, fma(-t0, h01, v1));
     const double u2 = fma(-t1, h12, fma(-t0, h02, v2));
@@ -579,7 +576,9 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
         F[3 * r + 2] = fma(-br, u2, f[r][2]);
     }
     // a lane's result never depends on which other lanes share its wave: fine lanes keep the short path's numbers
-    if (some_not_fine) {
+    if (__any(!fine)) {  // wave-uniform
+        double Fs[9];
+        rank2_project_sweeps(f_in, Fs);
 #pragma unroll
         for (int i = 0; i < 9; ++i) F[i] = fine ? F[i] : Fs[i];
     }

@@ -552,7 +552,7 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
                                                  int h0, int H, int32_t* __restrict__ counts,
                                                  double* __restrict__ errsums, double (*s_part)[WAVES][64],
                                                  int (*s_cnt)[WAVES]) {
-    static_assert(HB == 8 && WAVES == SLAM_SLICES, "wave j folds hypothesis j; the slices are the eight waves");
+    static_assert((HB == 8 || HB == 4) && WAVES == SLAM_SLICES, "wave j folds hypothesis j; the slices are the eight waves");
     constexpr int THREADS = 64 * WAVES;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // (the lane number is recomputed where it is needed instead of being kept in a register across the loop)
@@ -582,9 +582,9 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
             // The two waves of a SIMD issue oldest first; left alone, the older wave runs at the rate of a wave that
             // has the SIMD to itself and the younger one finishes its last third alone, at that same (slower) rate.
             // The wave that is behind gets the higher priority, so both stay within two hypotheses of each other.
-            if (j < 2) __builtin_amdgcn_s_setprio(3);       // (the loop is unrolled: one of these remains per turn)
-            else if (j < 4) __builtin_amdgcn_s_setprio(2);
-            else if (j < 6) __builtin_amdgcn_s_setprio(1);
+            if (j < HB / 4) __builtin_amdgcn_s_setprio(3);       // (the loop is unrolled: one of these remains per turn)
+            else if (j < HB / 2) __builtin_amdgcn_s_setprio(2);
+            else if (j < 3 * HB / 4) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
             double es = 0.0;
             cnt[j] = 0;
@@ -623,12 +623,14 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
         SLAM_STAMP(5);
         SLAM_STAMP_W8(2);
         // hypothesis `wave`: the slices in order on every lane position, then the tree over the lane positions
+        // (with fewer hypotheses than waves the surplus waves fold the last one again; their result is dropped)
+        const int hw = HB < WAVES ? min(wave, HB - 1) : wave;
         double pw[WAVES];
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) pw[w] = s_part[wave][w][lane];
+        for (int w = 0; w < WAVES; ++w) pw[w] = s_part[hw][w][lane];
         int c = 0;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) c += s_cnt[wave][w];
+        for (int w = 0; w < WAVES; ++w) c += s_cnt[hw][w];
         double t = pw[0];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) t += pw[w];
@@ -637,7 +639,7 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
         SLAM_STAMP_W8(3);
     }
     const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (lane == 0 && h0 + wave < H) {
+    if (lane == 0 && wave < HB && h0 + wave < H) {
         counts[h0 + wave] = ctotal;
         errsums[h0 + wave] = total;
     }
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
         p0 = a.n0; p1 = a.n1; N = a.N; H = a.H; Fout = a.F_all; counts = a.counts; errsums = a.errsums;
         if ((int)blockIdx.x * HB >= H) return;  // the grid is sized for the pair with most hypotheses
     }
-    static_assert(HB == 8 && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves eight hypotheses, eight lanes each");
+    static_assert((HB == 8 || HB == 4) && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves the hypotheses, eight lanes each");
     __shared__ double s_F[HB][9];
     __shared__ double s_part[HB][WAVES][64];  // partial sums p(w,l) of the eight hypotheses
     __shared__ int s_cnt[HB][WAVES];
@@ -848,11 +850,11 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
     // hold 64 registers, and with at most 128 two workgroups share a CU - one scores while the other one solves.
     MatchChunk<PPL, WAVES> first;
     if (wave == 0) {
-        const int g = lane >> 3, c = lane & 7;
+        const int g = (lane >> 3) & (HB - 1), c = lane & 7;  // (with four hypotheses the upper half of the wave repeats them)
         const int i = min(max(s_sel[g][c], 0), N - 1);  // never read outside the arrays, whatever idx holds
         double F[9];
         solve8_by_eight_lanes(p0[i], p1[i], F);
-        if (c == 0) {
+        if (c == 0 && lane < 8 * HB) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) s_F[g][q] = F[q];
             if (h0 + g < H) {

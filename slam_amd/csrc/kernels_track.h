@@ -242,49 +242,193 @@ __global__ __launch_bounds__(SLAM_RESECT_LANES) void k_resect(const double2* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5b: resection of six-point samples, sixteen lanes per hypothesis (four hypotheses per wave).
-//   The 12x12 design matrix needs no triangular factor here: lane c of a group holds column c of the matrix and
-//   column c of V in registers, and the one-sided Jacobi runs in tournament order - in each of the 11 rounds of a
-//   sweep the 12 columns form 6 disjoint pairs that rotate at the same time.  A lane fetches its partner's two
-//   columns with 48 ds_bpermute, both lanes of a pair derive the same angle from the same three sums, and each
-//   keeps its own side of the rotation.  Same thresholds as the one-lane kernel; sweeps end when no pair of the
-//   wave rotates.  Lanes 12..15 of a group idle.
+// K5b: resection of six-point samples, sixteen lanes per hypothesis (four hypotheses per wave): lane c of a group
+// holds column c of the 12x12 design matrix; lanes 12..15 of a group carry zeros.
+//
+// The least right singular vector comes from a block inverse iteration on the triangular factor:
+//   1. Householder QR across the lanes (lane j forms reflector j, DPP row broadcasts carry it to the group, lane c > j
+//      applies it to its column): lane c ends with column c of R; an LDS transpose gives lane i row i as well.
+//   2. Two vectors x, y (one component per lane) go through (R^T R)^-1 = two triangular solves per step - at step j
+//      lane j's component is final and is broadcast, the other lanes subtract their multiple - and are orthonormalised
+//      after every step.  The pair converges to the span of the two least singular vectors at the rate
+//      (sigma_11 / sigma_10)^2 per step (0.01 at the 90th percentile of six-point samples, 0.27 at worst), where a single
+//      vector would converge at (sigma_12 / sigma_11)^2 (0.43 at the 99th percentile, 0.92 at worst).
+//   3. One rotation of R [x y] (one-sided Jacobi, 2 columns) separates the least vector inside the span.
+// Orthogonal transforms and triangular solves only: the Gram matrix, whose condition number would be the square of
+// 1e5..1e7, never appears.  A wave in which some group's vector fails the residual test at the end (or is not finite)
+// repeats the work with the one-sided Jacobi SVD below and keeps that result for those groups.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, const double* __restrict__ X3,
-                                                const int32_t* __restrict__ idx, int H, const double* __restrict__ tw,
-                                                double* __restrict__ hyp) {
-    const int lane = threadIdx.x;
-    const int c = lane & 15;                  // column owned by this lane
-    const int base = lane & 48;               // first lane of the group
-    const int h = blockIdx.x * 4 + (lane >> 4);
-    const bool owner = c < 12 && h < H;
-    const int hh = h < H ? h : H - 1;
-    double a[12], v[12];
-    // column c of the design matrix: rows 2p = [0,0,0,0, -Xh, v Xh], rows 2p+1 = [Xh, 0,0,0,0, -u Xh]
+#ifndef SLAM_RESECT_STEPS
+#define SLAM_RESECT_STEPS 16
+#endif
+
+template <int J>
+__device__ __forceinline__ double row16_bcast(double x) {  // x of lane J of each row of 16 lanes
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + J, 0xF, 0xF, false);  // row_newbcast:J
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + J, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double row16_sum(double v) {  // sum over the row of 16 lanes, on every lane, fixed order
+    v += dpp_f64<0xB1>(v);   // lane ^ 1
+    v += dpp_f64<0x4E>(v);   // lane ^ 2
+    v += dpp_f64<0x141>(v);  // 7 - l within 8
+    v += dpp_f64<0x140>(v);  // 15 - l within 16
+    return v;
+}
+
+template <int J>
+__device__ __forceinline__ void resect_qr_step(double (&a)[12], int c) {
+    double sigma = 0.0;
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
-        const int i = idx[(size_t)hh * 6 + p];
-        const double2 q = uv[i];
-        const int k = c & 3;
-        const double xk = k == 3 ? 1.0 : X3[3 * (size_t)i + k];
-        const int blk = c >> 2;               // 0: first four columns, 1: middle, 2: last (3 for idle lanes)
-        a[2 * p] = blk == 1 ? -xk : (blk == 2 ? q.y * xk : 0.0);
-        a[2 * p + 1] = blk == 0 ? xk : (blk == 2 ? -q.x * xk : 0.0);
+    for (int r = J + 1; r < 12; ++r) sigma = fma(a[r], a[r], sigma);
+    const double x0 = a[J];
+    const double s2 = fma(x0, x0, sigma);
+    const double normx = (s2 > 0.0) ? s2 * rsqrt(s2) : 0.0;
+    const double alpha = (x0 >= 0.0) ? -normx : normx;
+    const double v0 = x0 - alpha;  // same sign as x0: no cancellation
+    const double vtv = fma(v0, v0, sigma);
+    const double bj = (vtv > 0.0) ? 2.0 * fast_rcp(vtv) : 0.0;
+    const double rv0 = row16_bcast<J>(v0), rb = row16_bcast<J>(bj);
+    double tail[12];
+#pragma unroll
+    for (int r = J + 1; r < 12; ++r) tail[r] = row16_bcast<J>(a[r]);
+    if (c > J) {
+        double s = rv0 * a[J];
+#pragma unroll
+        for (int r = J + 1; r < 12; ++r) s = fma(tail[r], a[r], s);
+        s *= rb;
+        a[J] = fma(-s, rv0, a[J]);
+#pragma unroll
+        for (int r = J + 1; r < 12; ++r) a[r] = fma(-s, tail[r], a[r]);
     }
+    if (c == J) a[J] = alpha;
+}
+
+// R w = z for two right-hand sides at once, one component per lane: rowz[j] = R[i][j] for j > i (0 otherwise) on lane i
+template <int J>
+__device__ __forceinline__ void resect_back_step(const double (&rowz)[12], double rd, double& ax, double& ay) {
+    const double bx = row16_bcast<J>(ax * rd), by = row16_bcast<J>(ay * rd);
+    ax = fma(-rowz[J], bx, ax);
+    ay = fma(-rowz[J], by, ay);
+    if constexpr (J > 0) resect_back_step<J - 1>(rowz, rd, ax, ay);
+}
+// R^T z = x likewise: colz[j] = R[j][i] for j < i (0 otherwise) on lane i
+template <int J>
+__device__ __forceinline__ void resect_fwd_step(const double (&colz)[12], double rd, double& ax, double& ay) {
+    const double bx = row16_bcast<J>(ax * rd), by = row16_bcast<J>(ay * rd);
+    ax = fma(-colz[J], bx, ax);
+    ay = fma(-colz[J], by, ay);
+    if constexpr (J < 11) resect_fwd_step<J + 1>(colz, rd, ax, ay);
+}
+
+__device__ __forceinline__ void resect_orthonormalise(double& x, double& y) {
+    const double xx = row16_sum(x * x);
+    x *= rsqrt(xx);
+    const double xy = row16_sum(x * y);
+    y = fma(-xy, x, y);
+    const double yy = row16_sum(y * y);
+    y *= rsqrt(yy);
+}
+
+// a: this lane's column of the design matrix (destroyed).  cam: the least right singular vector, on every lane of the
+// group.  Returns false for a group whose result is not to be trusted.
+__device__ __forceinline__ bool resect6_block_iteration(double (&a)[12], int c, double (*s_R)[16], double (&cam)[12]) {
+    resect_qr_step<0>(a, c); resect_qr_step<1>(a, c); resect_qr_step<2>(a, c); resect_qr_step<3>(a, c);
+    resect_qr_step<4>(a, c); resect_qr_step<5>(a, c); resect_qr_step<6>(a, c); resect_qr_step<7>(a, c);
+    resect_qr_step<8>(a, c); resect_qr_step<9>(a, c); resect_qr_step<10>(a, c);
+    // lane c: a[r] = R[r][c] for r <= c.  Rows through LDS: s_R[r][c]
+#pragma unroll
+    for (int r = 0; r < 12; ++r) s_R[r][c] = a[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int i = c < 12 ? c : 11;
+    double rowz[12], colz[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const double rij = s_R[i][j];
+        rowz[j] = (c < 12 && j > c) ? rij : 0.0;
+        colz[j] = (c < 12 && j < c) ? a[j] : 0.0;
+    }
+    double diag = 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) diag = (j == c) ? a[j] : diag;
+    const double rd = (diag != 0.0) ? fast_rcp(diag) : 0.0;
+
+    double x = c < 12 ? 1.0 : 0.0, y = c < 12 ? ((c & 1) ? -1.0 : 1.0) : 0.0;
+    resect_back_step<11>(rowz, rd, x, y);
+    x *= rd; y *= rd;
+    resect_orthonormalise(x, y);
+#pragma unroll 1
+    for (int k = 0; k < SLAM_RESECT_STEPS; ++k) {
+        resect_fwd_step<0>(colz, rd, x, y);
+        x *= rd; y *= rd;
+        resect_back_step<11>(rowz, rd, x, y);
+        x *= rd; y *= rd;
+        resect_orthonormalise(x, y);
+    }
+    // B = R [x y], one component per lane
+    double xr[12], yr[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) xr[j] = 0.0, yr[j] = 0.0;
+    xr[0] = row16_bcast<0>(x); yr[0] = row16_bcast<0>(y);    xr[1] = row16_bcast<1>(x); yr[1] = row16_bcast<1>(y);
+    xr[2] = row16_bcast<2>(x); yr[2] = row16_bcast<2>(y);    xr[3] = row16_bcast<3>(x); yr[3] = row16_bcast<3>(y);
+    xr[4] = row16_bcast<4>(x); yr[4] = row16_bcast<4>(y);    xr[5] = row16_bcast<5>(x); yr[5] = row16_bcast<5>(y);
+    xr[6] = row16_bcast<6>(x); yr[6] = row16_bcast<6>(y);    xr[7] = row16_bcast<7>(x); yr[7] = row16_bcast<7>(y);
+    xr[8] = row16_bcast<8>(x); yr[8] = row16_bcast<8>(y);    xr[9] = row16_bcast<9>(x); yr[9] = row16_bcast<9>(y);
+    xr[10] = row16_bcast<10>(x); yr[10] = row16_bcast<10>(y); xr[11] = row16_bcast<11>(x); yr[11] = row16_bcast<11>(y);
+    double bx = diag * x, by = diag * y;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { bx = fma(rowz[j], xr[j], bx); by = fma(rowz[j], yr[j], by); }
+    const double sa = row16_sum(bx * bx), sb = row16_sum(by * by), sc = row16_sum(bx * by);
+    double cs = 1.0, sn = 0.0;
+    if (sc * sc > 1e-30 * (sa * sb)) jacobi_angle(sa, sb, sc, cs, sn);
+    // rotated pair: p' = cs p - sn q, q' = sn p + cs q; the shorter image belongs to the least singular vector
+    const double bu = fma(cs, bx, -sn * by), bw = fma(sn, bx, cs * by);
+    const double nu = row16_sum(bu * bu), nw = row16_sum(bw * bw);
+    const bool first = nu <= nw;
+    const double v = first ? fma(cs, x, -sn * y) : fma(sn, x, cs * y);
+    // One more step for v alone, as refinement and as test: if v = v12 + e v11, the step leaves e rho with
+    // rho = (sigma_12 / sigma_11)^2 ~ nv / nother, so v moves by e (1 - rho).  (A residual R^T R v - nv v would carry
+    // rounding errors of the size of sigma_1^2, the Gram matrix' trouble again; a solve does not.)
+    const double nv = first ? nu : nw, nother = first ? nw : nu;
+    double v1 = v, dummy = 0.0;
+    resect_fwd_step<0>(colz, rd, v1, dummy);
+    v1 *= rd; dummy *= rd;
+    resect_back_step<11>(rowz, rd, v1, dummy);
+    v1 *= rd;
+    const double n1 = row16_sum(v1 * v1);
+    v1 *= rsqrt(n1);
+    const double dv = v1 - v;
+    const double moved = row16_sum(dv * dv);
+    const double slack = 1.0 - nv / nother;
+    cam[0] = row16_bcast<0>(v1); cam[1] = row16_bcast<1>(v1); cam[2] = row16_bcast<2>(v1); cam[3] = row16_bcast<3>(v1);
+    cam[4] = row16_bcast<4>(v1); cam[5] = row16_bcast<5>(v1); cam[6] = row16_bcast<6>(v1); cam[7] = row16_bcast<7>(v1);
+    cam[8] = row16_bcast<8>(v1); cam[9] = row16_bcast<9>(v1); cam[10] = row16_bcast<10>(v1); cam[11] = row16_bcast<11>(v1);
+    const bool fine = (moved < 1e-16 * slack * slack) && (n1 > 0.0) && (n1 < 1e300);  // false for NaN as well
+#ifdef SLAM_RESECT_DEBUG
+    if (c == 0 && !fine) printf("not fine: block %d group %d moved %.3e slack %.3e nu %.3e nw %.3e\n", (int)blockIdx.x, (int)(threadIdx.x >> 4), moved, slack, nu, nw);
+#endif
+    return fine;
+}
+
+// The one-sided Jacobi SVD of the same matrix (the fallback, and the reference point for the iteration above): the
+// columns rotate in tournament order - in each of the 11 rounds of a sweep the 12 columns form 6 disjoint pairs that
+// rotate at the same time.  A lane fetches its partner's columns with ds_bpermute, both lanes of a pair derive the
+// same angle from the same three sums, and each keeps its own side of the rotation.  Works on the matrix itself; sweeps
+// end when no pair of the wave rotates.  cam: the right singular vector of the smallest singular value, on every lane
+// of the group.
+__device__ __forceinline__ void resect6_jacobi(double (&a)[12], int c, int base, double (&cam)[12]) {
+    double v[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) v[i] = (i == c) ? 1.0 : 0.0;
-    if (c >= 12) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) a[i] = 0.0;
-    }
-    // squared Frobenius norm of the group's matrix -> rounding floor
     double n2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 12; ++i) n2 = fma(a[i], a[i], n2);
     double fro2 = n2;
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) fro2 += __shfl_xor(fro2, m, 64);
-    const double floor2 = fro2 * 1e-32;
+    const double floor2 = fro2 * 1e-32;  // columns at rounding level are left alone
 
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool rotated = false;
@@ -347,7 +491,49 @@ __global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, 
         best = take ? ob : best;
         who = take ? ow : who;
     }
-    if (owner && who == c) resect_finish(v, tw, hyp + (size_t)h * HP_LEN);  // vh[-1].reshape(3,4)   :113-114
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cam[i] = __shfl(v[i], base + who, 64);  // vh[-1]   :113-114
+}
+
+// column c of the design matrix of hypothesis hh: rows 2p = [0,0,0,0, -Xh, v Xh], rows 2p+1 = [Xh, 0,0,0,0, -u Xh]
+__device__ __forceinline__ void resect6_column(const double2* __restrict__ uv, const double* __restrict__ X3,
+                                               const int32_t* __restrict__ idx, int hh, int c, double (&a)[12]) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const int i = idx[(size_t)hh * 6 + p];
+        const double2 q = uv[i];
+        const int k = c & 3;
+        const double xk = k == 3 ? 1.0 : X3[3 * (size_t)i + k];
+        const int blk = c >> 2;               // 0: first four columns, 1: middle, 2: last (3 for idle lanes)
+        a[2 * p] = blk == 1 ? -xk : (blk == 2 ? q.y * xk : 0.0);
+        a[2 * p + 1] = blk == 0 ? xk : (blk == 2 ? -q.x * xk : 0.0);
+    }
+    if (c >= 12) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a[i] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, const double* __restrict__ X3,
+                                                const int32_t* __restrict__ idx, int H, const double* __restrict__ tw,
+                                                double* __restrict__ hyp) {
+    __shared__ double s_R[4][12][16];
+    const int lane = threadIdx.x;
+    const int c = lane & 15;                  // column owned by this lane
+    const int base = lane & 48;               // first lane of the group
+    const int h = blockIdx.x * 4 + (lane >> 4);
+    const int hh = h < H ? h : H - 1;
+    double a[12], cam[12];
+    resect6_column(uv, X3, idx, hh, c, a);
+    const bool fine = resect6_block_iteration(a, c, s_R[lane >> 4], cam);
+    if (__any(!fine)) {  // wave-uniform; a group that was fine keeps its numbers
+        double cam2[12];
+        resect6_column(uv, X3, idx, hh, c, a);
+        resect6_jacobi(a, c, base, cam2);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cam[i] = fine ? cam[i] : cam2[i];
+    }
+    if (c == 0 && h < H) resect_finish(cam, tw, hyp + (size_t)h * HP_LEN);  // vh[-1].reshape(3,4)   :113-114
 }
 
 // fills the call's work block: K prev_pose[:3], prev_pose[:3], K.  kp.A = K, kp.B unused; prev (12) by value too.
@@ -455,7 +641,7 @@ __global__ __launch_bounds__(256) void k_triangulate_cams(const double* __restri
     if (i >= N) return;
     const double2 a = p0[i], b = p1[i];
     double X[3];
-    triangulate_one(cams, cams + 12, a.x, a.y, b.x, b.y, X);
+    triangulate_one(cams, cams + 12, a.x, a.y, b.x, b.y, X, SLAM_TRI_ANGLE_TOL_TIGHT);
     Xout[3 * i + 0] = X[0];
     Xout[3 * i + 1] = X[1];
     Xout[3 * i + 2] = X[2];

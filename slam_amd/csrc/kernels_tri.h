@@ -40,8 +40,15 @@ __device__ __forceinline__ double rcp_like_division(double x) {
     return x == 0.0 ? __builtin_amdgcn_rcp(x) : r;
 }
 
+// angle_tol: rotation angle below which the polish of the least singular vector stops.  1e-12 serves cameras of the
+// form K [R|t] (pose recovery, hypothesis scoring: the points then agree with LAPACK's to 1e-11); callers whose
+// cameras are arbitrary - the reference's tracking step triangulates with the POSES themselves against pixel
+// coordinates (src/triangulation.py:179), which leaves the two smallest singular values close together and the
+// homogeneous coordinate small - pass SLAM_TRI_ANGLE_TOL_TIGHT.
+#define SLAM_TRI_ANGLE_TOL_TIGHT 1e-15
 __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, const double* __restrict__ P1, double u0,
-                                                double v0, double u1, double v1, double (&X)[3]) {
+                                                double v0, double u1, double v1, double (&X)[3],
+                                                double angle_tol = SLAM_TRI_ANGLE_TOL) {
     double D[4][4], m[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -61,7 +68,7 @@ __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, c
         for (int j = 0; j < 4; ++j) D[i][j] *= im[j];
     // polished until further rotations would turn y by less than 1e-12 rad (the points are compared to 1e-5)
     double yv[4];
-    least_right_vector_4x4(D, SLAM_TRI_ANGLE_TOL, yv);
+    least_right_vector_4x4(D, angle_tol, yv);
     double Y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Y[i] = m[i] * yv[i];
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* _
     if (i >= N) return;
     const double2 a = p0[i], b = p1[i];
     double X[3];
-    triangulate_one(cams.P0, cams.P1, a.x, a.y, b.x, b.y, X);
+    triangulate_one(cams.P0, cams.P1, a.x, a.y, b.x, b.y, X, SLAM_TRI_ANGLE_TOL_TIGHT);
     Xout[3 * i + 0] = X[0];
     Xout[3 * i + 1] = X[1];
     Xout[3 * i + 2] = X[2];

@@ -33,6 +33,19 @@ int main(int argc, char** argv) {
         if (!f || fread(p0.data(), 8, 2 * N, f) != (size_t)(2 * N) || fread(p1.data(), 8, 2 * N, f) != (size_t)(2 * N)) return 1;
         fclose(f);
     }
+    // DUMMY_QUEUES=k: k streams of the default priority are created and used once before the library's context exists
+    // (each makes the runtime create a hardware queue), to see how the order in which a process creates its queues
+    // changes which of the library's streams can run side by side
+    if (const char* dq = getenv("DUMMY_QUEUES")) {
+        for (int q = 0; q < atoi(dq); ++q) {
+            hipStream_t st;
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            long long* tmp;
+            hipMalloc(&tmp, 16);
+            hipLaunchKernelGGL(k_freq, dim3(1), dim3(64), 0, st, 10LL, tmp);
+            hipStreamSynchronize(st);
+        }
+    }
     slam_ctx* ctx;
     if (slam_create(0, &ctx)) return 1;
     double *d_p0, *d_p1, *rec;

@@ -88,6 +88,25 @@ def ransac(p0, p1, idx, thr=0.005, threads=1, want_F=True, want_mask=True):
                 best_count=int(counts[bi.value]), best_errsum=float(errsums[bi.value]))
 
 
+def ransac_timed(p0, p1, idx, thr=0.005, threads=1, reps=5):
+    """Best and mean seconds per pass of `ransac` over `reps` passes after one warm-up pass, timed inside the C
+    library on the monotonic clock; also the winner's index (for a check against the GPU)."""
+    p0, p1, idx = _c(p0), _c(p1), _c(idx, np.int32)
+    H, N = len(idx), len(p0)
+    counts = np.empty(H, dtype=np.int32)
+    errsums = np.empty(H)
+    bi = C.c_int32(-1)
+    best, mean = C.c_double(0), C.c_double(0)
+    fn = lib().oracle_ransac_timed
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                   C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rc = fn(p0.ctypes.data, p1.ctypes.data, N, idx.ctypes.data, H, thr, threads, reps, counts.ctypes.data,
+            errsums.ctypes.data, C.byref(bi), C.byref(best), C.byref(mean))
+    assert rc == 0
+    return dict(best_seconds=best.value, mean_seconds=mean.value, best_index=int(bi.value))
+
+
 def normalize_points(p):
     p = _c(p)
     out = np.empty_like(p)

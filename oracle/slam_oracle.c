@@ -290,6 +290,32 @@ int oracle_ransac(const double* p0, const double* p1, int N, const int32_t* idx,
     return 0;
 }
 
+/* Timing leg of the benchmark's CPU baseline: one untimed pass, then `reps` timed passes of oracle_ransac on the
+ * monotonic clock; returns the best and the mean time of a pass in seconds (what a stopwatch around the foreign-function
+ * call would add is left out). */
+#include <time.h>
+int oracle_ransac_timed(const double* p0, const double* p1, int N, const int32_t* idx, int H, double thr, int threads,
+                        int reps, int32_t* counts /* H */, double* errsums /* H */, int32_t* best_index,
+                        double* best_seconds, double* mean_seconds) {
+    if (reps < 1) return -1;
+    int rc = oracle_ransac(p0, p1, N, idx, H, thr, NULL, counts, errsums, best_index, NULL, NULL, threads);
+    if (rc) return rc;
+    double best = 1e300, total = 0.0;
+    for (int r = 0; r < reps; r++) {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        rc = oracle_ransac(p0, p1, N, idx, H, thr, NULL, counts, errsums, best_index, NULL, NULL, threads);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (rc) return rc;
+        const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (dt < best) best = dt;
+        total += dt;
+    }
+    *best_seconds = best;
+    *mean_seconds = total / reps;
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------
  * caller-side normalisation: custom_slam.py:85-93
  * ---------------------------------------------------------------------------------- */

@@ -353,7 +353,13 @@ __device__ __forceinline__ bool resect6_block_iteration(double (&a)[12], int c, 
     double diag = 0.0;
 #pragma unroll
     for (int j = 0; j < 12; ++j) diag = (j == c) ? a[j] : diag;
-    const double rd = (diag != 0.0) ? fast_rcp(diag) : 0.0;
+    // A (numerically) zero diagonal entry - a rank-deficient sample, whose null vector is exactly what is wanted -
+    // is replaced by a tiny one, as inverse iteration does with zero pivots: the solves then blow the null direction up
+    // by 1e18 per solve instead of dividing by zero (or, with a reciprocal of 0, losing that direction altogether).
+    const double d2 = row16_sum(diag * diag);
+    const double tiny = 1e-18 * sqrt(d2);
+    const double diag_used = (c < 12 && fabs(diag) < tiny) ? tiny : diag;
+    const double rd = (diag_used != 0.0) ? fast_rcp(diag_used) : 0.0;
 
     double x = c < 12 ? 1.0 : 0.0, y = c < 12 ? ((c & 1) ? -1.0 : 1.0) : 0.0;
     resect_back_step<11>(rowz, rd, x, y);

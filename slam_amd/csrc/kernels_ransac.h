@@ -804,13 +804,8 @@ __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifdef SLAM_RANSAC_VGPRS
-#define SLAM_RANSAC_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SLAM_RANSAC_VGPRS)))
-#else
-#define SLAM_RANSAC_VGPR_ATTR
-#endif
 template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
-__global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32) / WAVES) SLAM_RANSAC_VGPR_ATTR void k_ransac(
+__global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32) / WAVES) void k_ransac(
     const double2* __restrict__ p0, const double2* __restrict__ p1, int N, const int32_t* __restrict__ idx_in,
     uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw, int64_t raw_it0, double rcut,
     double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags,

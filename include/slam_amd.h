@@ -166,7 +166,8 @@ int slam_comm_init_rank(slam_ctx* ctx, const void* id128, int n_ranks, int rank)
 /* Hypothesis-sharded RANSAC: every rank passes the record its own range produced (device memory, SLAM_REC_LEN
  * doubles, e.g. d_record of slam_ransac_f_dev); after the call every rank's d_record holds the global winner:
  * all-gather of the records, then the rule above (more inliers, smaller inlier-error sum, earlier iteration) applied
- * by a kernel.  Asynchronous on the context's stream. */
+ * by a kernel.  Asynchronous on the context's stream, after everything the context has queued so far (with
+ * slam_set_concurrency(n > 1) that stream first waits, on the device, for the internal streams). */
 int slam_exchange_winner_dev(slam_ctx* ctx, void* rccl_comm, double* d_record);
 /* Point-sharded pose recovery: sums the four in-front counts of slam_pose_candidates_dev over the ranks in place
  * (int64[4], device memory), between that call and slam_pose_select_dev.  Asynchronous on the context's stream. */

@@ -861,10 +861,24 @@ extern "C" int slam_merge_records(const double* records, int n_records, double* 
 // ================================================================================================
 // exchange step of the sharded runs (RCCL)
 // ================================================================================================
+// The exchange runs on the context's ordered stream.  With slam_set_concurrency(n > 1) the RANSAC calls before it ran
+// on the internal streams: the ordered stream waits (on the device, not on the host) for what they have queued so far.
+static int join_lanes(slam_ctx* ctx) {
+    if (ctx->stream != ctx->own_stream || ctx->lanes_in_use <= 1) return SLAM_OK;
+    for (int l = 1; l < ctx->lanes_in_use; ++l) {
+        if (!ctx->lane_stream[l] || ctx->lane_stream[l] == ctx->stream) continue;
+        if (!ctx->lane_event[l]) SLAM_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_event[l], hipEventDisableTiming));
+        SLAM_HIP(ctx, hipEventRecord(ctx->lane_event[l], ctx->lane_stream[l]));
+        SLAM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_event[l], 0));
+    }
+    return SLAM_OK;
+}
+
 extern "C" int slam_merge_records_dev(slam_ctx* ctx, const double* d_records, int n_records, double* d_out) {
     if (!ctx) return SLAM_EINVAL;
     SLAM_REQUIRE(ctx, d_records && d_out && n_records >= 1, "NULL pointer or no records");
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    SLAM_TRY(join_lanes(ctx));
     ctx->cur = ctx->stream;
     return slam_launch(ctx, -1, slamx::k_merge_records, dim3(1), dim3(64), 0, d_records, n_records, d_out);
 }
@@ -918,6 +932,7 @@ extern "C" int slam_exchange_winner_dev(slam_ctx* ctx, void* rccl_comm, double* 
     int n_ranks = 0;
     SLAM_TRY(exchange_comm(ctx, rccl_comm, &comm, &n_ranks));
     SLAM_TRY(slam_reserve(ctx, ctx->xchg, (size_t)n_ranks * SLAM_REC_LEN * sizeof(double)));  // grows for a caller's communicator only
+    SLAM_TRY(join_lanes(ctx));
     SLAM_RCCL(ctx, slamx::rccl().AllGather(d_record, ctx->xchg.p, SLAM_REC_LEN, slamx::kNcclFloat64, comm, ctx->stream));
     ctx->cur = ctx->stream;
     return slam_launch(ctx, -1, slamx::k_merge_records, dim3(1), dim3(64), 0, (const double*)ctx->xchg.p, n_ranks, d_record);
@@ -930,6 +945,7 @@ extern "C" int slam_allreduce_counts4_dev(slam_ctx* ctx, void* rccl_comm, int64_
     slamx::ncclComm_t comm;
     int n_ranks = 0;
     SLAM_TRY(exchange_comm(ctx, rccl_comm, &comm, &n_ranks));
+    SLAM_TRY(join_lanes(ctx));
     SLAM_RCCL(ctx, slamx::rccl().AllReduce(d_counts4, d_counts4, 4, slamx::kNcclInt64, slamx::kNcclSum, comm, ctx->stream));
     return SLAM_OK;
 }

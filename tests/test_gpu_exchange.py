@@ -78,6 +78,45 @@ def test_exchange_with_one_rank_keeps_the_record(comm_ctx):
     assert counts.cpu().tolist() == [5, 1 << 40, 7, 0]
 
 
+def test_merge_after_calls_on_the_internal_streams(comm_ctx):
+    """With several calls in flight (slam_set_concurrency) the RANSAC calls run on the context's internal streams; a
+    merge or an exchange queued right after them, without a synchronisation, still sees their records: records of four
+    hypothesis ranges, merged on the device, equal the record of the whole range."""
+    import torch
+    from slam_amd import synth
+    from oracle import slam_oracle as so
+    ctx = comm_ctx
+    dev = torch.device("cuda", ctx.device)
+    d = synth.make_pair(4096, 0.3, seed=22)
+    n0, _ = so.normalize_points(d["pts0"])
+    n1, _ = so.normalize_points(d["pts1"])
+    p0, p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+    H = 4096
+    whole = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    parts = torch.zeros((4, _lib.REC_LEN), dtype=torch.float64, device=dev)
+    out = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    def call(it0, n, rec):
+        ctx.check(ctx.lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), 4096, None, _lib.SAMPLER_COUNTER, 11,
+                                            it0, n, _lib.DEFAULT_THRESHOLD, rec, None, None, None, None))
+    call(0, H, whole.data_ptr())
+    ctx.check(ctx.lib.slam_synchronize(ctx.handle))
+    ctx.check(ctx.lib.slam_set_concurrency(ctx.handle, 4))
+    try:
+        for rep in range(5):
+            parts.zero_()
+            torch.cuda.synchronize()
+            for k in range(4):
+                call(k * (H // 4), H // 4, parts[k].data_ptr())
+            ctx.check(ctx.lib.slam_merge_records_dev(ctx.handle, parts.data_ptr(), 4, out.data_ptr()))
+            pipeline.exchange_winner_dev(ctx, out.data_ptr())
+            ctx.check(ctx.lib.slam_synchronize(ctx.handle))
+            assert torch.equal(out, whole), rep
+    finally:
+        ctx.check(ctx.lib.slam_set_concurrency(ctx.handle, 1))
+
+
 def test_exchange_without_communicator_is_an_error():
     import torch
     ctx = _lib.Context()

@@ -36,7 +36,7 @@ __device__ __forceinline__ double det3x3(const double (&m)[9]) {
 
 // From the least right singular vector of the design matrix to the hypothesis block   (reference:
 // src/triangulation.py:113-132, src/util.py:18-37,60-66)
-__device__ inline void resect_finish(double (&cam)[12], const double* __restrict__ tw, double* __restrict__ hp) {
+__device__ inline void resect_finish(double (&cam)[12], const double* __restrict__ K, double* __restrict__ hp) {
     // :115  sign so that det of the left 3x3 block is positive
     const double m3[9] = {cam[0], cam[1], cam[2], cam[4], cam[5], cam[6], cam[8], cam[9], cam[10]};
     const double d = det3x3(m3);
@@ -121,7 +121,6 @@ __device__ inline void resect_finish(double (&cam)[12], const double* __restrict
 #pragma unroll
     for (int i = 0; i < 12; ++i) hp[HP_POSE + i] = pose[i];
     hp[HP_POSE + 12] = 0.0; hp[HP_POSE + 13] = 0.0; hp[HP_POSE + 14] = 0.0; hp[HP_POSE + 15] = 1.0;
-    const double* __restrict__ K = tw + TW_K;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(SLAM_RESECT_LANES) void k_resect(const double2* __r
 #undef R_
 #undef V_
 
-    resect_finish(cam, tw, hyp + (size_t)h * HP_LEN);
+    resect_finish(cam, tw + TW_K, hyp + (size_t)h * HP_LEN);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -520,11 +519,31 @@ __device__ __forceinline__ void resect6_column(const double2* __restrict__ uv, c
     }
 }
 
+// The call's work block: K prev_pose[:3], prev_pose[:3], K, and prev_pose[:3] as the first camera of the final
+// triangulation.  The intrinsics and the previous pose travel as a kernel argument.
+struct TrackSetup {
+    double K[9];
+    double prev[12];
+};
+__device__ __forceinline__ void track_setup(const TrackSetup& s, double* __restrict__ tw, int t) {
+    if (t < 12) {
+        const int i = t >> 2, j = t & 3;
+        tw[TW_P0 + t] = s.K[3 * i] * s.prev[j] + s.K[3 * i + 1] * s.prev[4 + j] + s.K[3 * i + 2] * s.prev[8 + j];
+        tw[TW_PREV + t] = s.prev[t];
+        tw[TW_WIN + t] = s.prev[t];
+    }
+    if (t < 9) tw[TW_K + t] = s.K[t];
+}
+__global__ __launch_bounds__(64) void k_track_setup(TrackSetup s, double* __restrict__ tw) { track_setup(s, tw, threadIdx.x); }
+
+// setup: the kernels after this one read the work block tw; workgroup 0 fills it on the way (this kernel itself takes
+// the intrinsics from the argument), which saves the tracking step a launch.
 __global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, const double* __restrict__ X3,
-                                                const int32_t* __restrict__ idx, int H, const double* __restrict__ tw,
-                                                double* __restrict__ hyp) {
+                                                const int32_t* __restrict__ idx, int H, TrackSetup setup,
+                                                double* __restrict__ tw, double* __restrict__ hyp) {
     __shared__ double s_R[4][12][16];
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0) track_setup(setup, tw, lane);
     const int c = lane & 15;                  // column owned by this lane
     const int base = lane & 48;               // first lane of the group
     const int h = blockIdx.x * 4 + (lane >> 4);
@@ -539,23 +558,7 @@ __global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, 
 #pragma unroll
         for (int i = 0; i < 12; ++i) cam[i] = fine ? cam[i] : cam2[i];
     }
-    if (c == 0 && h < H) resect_finish(cam, tw, hyp + (size_t)h * HP_LEN);  // vh[-1].reshape(3,4)   :113-114
-}
-
-// fills the call's work block: K prev_pose[:3], prev_pose[:3], K.  kp.A = K, kp.B unused; prev (12) by value too.
-struct TrackSetup {
-    double K[9];
-    double prev[12];
-};
-__global__ __launch_bounds__(64) void k_track_setup(TrackSetup s, double* __restrict__ tw) {
-    const int t = threadIdx.x;
-    if (t < 12) {
-        const int i = t >> 2, j = t & 3;
-        tw[TW_P0 + t] = s.K[3 * i] * s.prev[j] + s.K[3 * i + 1] * s.prev[4 + j] + s.K[3 * i + 2] * s.prev[8 + j];
-        tw[TW_PREV + t] = s.prev[t];
-        tw[TW_WIN + t] = s.prev[t];
-    }
-    if (t < 9) tw[TW_K + t] = s.K[t];
+    if (c == 0 && h < H) resect_finish(cam, setup.K, hyp + (size_t)h * HP_LEN);  // vh[-1].reshape(3,4)   :113-114
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,25 +606,26 @@ __global__ __launch_bounds__(256) void k_track_score(const double* __restrict__ 
 //   a later hypothesis replaces the incumbent iff it has more points in front, or as many and a strictly smaller
 //   error.  Each lane scans a contiguous range in order, lane 0 then folds the 64 range winners in order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_track_select(const int32_t* __restrict__ counts, const double* __restrict__ errs,
-                                                     int H, const double* __restrict__ hyp, double* __restrict__ tw,
-                                                     double* __restrict__ pose_out) {
-    __shared__ int s_i[64];
-    __shared__ int s_c[64];
-    __shared__ double s_e[64];
+// (the first 64 threads of the workgroup take part; the others wait at the barriers; returns the winner's position)
+__device__ __forceinline__ int track_select(const int32_t* __restrict__ counts, const double* __restrict__ errs, int H,
+                                            int* s_i, int* s_c, double* s_e, bool write, double* __restrict__ tw) {
     const int lane = threadIdx.x;
-    const int per = (H + 63) / 64;
-    const int lo = lane * per, hi = min(H, lo + per);
-    int bi = -1, bc = -1;
-    double be = 0.0;
-    for (int i = lo; i < hi; ++i) {
-        const int c = counts[i];
-        const double e = errs[i];
-        if (c > bc || (c == bc && be > e)) { bc = c; be = e; bi = i; }
+    if (lane < 64) {
+        const int per = (H + 63) / 64;
+        const int lo = lane * per, hi = min(H, lo + per);
+        int bi = -1, bc = -1;
+        double be = 0.0;
+        for (int i = lo; i < hi; ++i) {
+            const int c = counts[i];
+            const double e = errs[i];
+            if (c > bc || (c == bc && be > e)) { bc = c; be = e; bi = i; }
+        }
+        s_i[lane] = bi; s_c[lane] = bc; s_e[lane] = be;
     }
-    s_i[lane] = bi; s_c[lane] = bc; s_e[lane] = be;
     __syncthreads();
     if (lane == 0) {
+        int bi = s_i[0], bc = s_c[0];
+        double be = s_e[0];
         for (int l = 1; l < 64; ++l) {
             if (s_i[l] < 0) continue;
             const int c = s_c[l];
@@ -629,14 +633,61 @@ __global__ __launch_bounds__(64) void k_track_select(const int32_t* __restrict__
             if (c > bc || (c == bc && be > e)) { bc = c; be = e; bi = s_i[l]; }
         }
         s_i[0] = bi;
-        tw[TW_BEST] = (double)bi;
-        tw[TW_BEST + 1] = (double)bc;
-        tw[TW_BEST + 2] = be;
+        if (write) {
+            tw[TW_BEST] = (double)bi;
+            tw[TW_BEST + 1] = (double)bc;
+            tw[TW_BEST + 2] = be;
+        }
     }
     __syncthreads();
-    const double* __restrict__ hp = hyp + (size_t)s_i[0] * HP_LEN;
+    return s_i[0];
+}
+
+__global__ __launch_bounds__(64) void k_track_select(const int32_t* __restrict__ counts, const double* __restrict__ errs,
+                                                     int H, const double* __restrict__ hyp, double* __restrict__ tw,
+                                                     double* __restrict__ pose_out) {
+    __shared__ int s_i[64];
+    __shared__ int s_c[64];
+    __shared__ double s_e[64];
+    const int lane = threadIdx.x;
+    const int win = track_select(counts, errs, H, s_i, s_c, s_e, true, tw);
+    const double* __restrict__ hp = hyp + (size_t)win * HP_LEN;
     if (lane < 16) pose_out[lane] = hp[HP_POSE + lane];
     if (lane < 12) tw[TW_WIN + 12 + lane] = hp[HP_POSE + lane];
+}
+
+// K7 and the final triangulation in one launch (few hypotheses): every workgroup finds the winner for itself (12 bytes
+// per hypothesis) and triangulates its 256 matches with (prev_pose[:3], winning pose[:3])   (src/triangulation.py:
+// 172-182); workgroup 0 writes the winner's record and pose.  N may be 0 (one workgroup, selection only).
+__global__ __launch_bounds__(256) void k_track_finish(const int32_t* __restrict__ counts, const double* __restrict__ errs,
+                                                      int H, const double* __restrict__ hyp, double* __restrict__ tw,
+                                                      double* __restrict__ pose_out, const double2* __restrict__ p0,
+                                                      const double2* __restrict__ p1, int64_t N,
+                                                      double* __restrict__ Xout) {
+    __shared__ int s_i[64];
+    __shared__ int s_c[64];
+    __shared__ double s_e[64];
+    __shared__ double s_cams[24];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = i < N;
+    double2 a = make_double2(0.0, 0.0), b = a;
+    if (live) { a = p0[i]; b = p1[i]; }  // in flight during the selection
+    const int win = track_select(counts, errs, H, s_i, s_c, s_e, blockIdx.x == 0, tw);
+    const double* __restrict__ hp = hyp + (size_t)win * HP_LEN;
+    if (tid < 12) s_cams[tid] = tw[TW_WIN + tid];
+    else if (tid < 24) s_cams[tid] = hp[HP_POSE + tid - 12];
+    if (blockIdx.x == 0) {
+        if (tid < 16) pose_out[tid] = hp[HP_POSE + tid];
+        if (tid < 12) tw[TW_WIN + 12 + tid] = hp[HP_POSE + tid];
+    }
+    __syncthreads();
+    if (!live) return;
+    double X[3];
+    triangulate_one(s_cams, s_cams + 12, a.x, a.y, b.x, b.y, X, SLAM_TRI_ANGLE_TOL_TIGHT);
+    Xout[3 * i + 0] = X[0];
+    Xout[3 * i + 1] = X[1];
+    Xout[3 * i + 2] = X[2];
 }
 
 // triangulation whose camera pair sits in device memory (the tracking step's last call: src/triangulation.py:179-182)

@@ -1387,7 +1387,9 @@ extern "C" int slam_pose_from_points(slam_ctx* ctx, const double* image_points, 
     return SLAM_OK;
 }
 
-// queues sample -> resect -> score -> select -> final triangulation; everything stays on the device
+// queues sample -> resect -> score -> select + final triangulation; everything stays on the device
+// (with more hypotheses than this every workgroup of the final triangulation would repeat a long selection scan: two launches then)
+#define SLAM_TRACK_FUSED_FINISH_MAX_H 2048
 static int track_enqueue(slam_ctx* ctx, const double* previous_pose, const double* d_a, const double* d_b,
                          const double* d_X3, int M, const double* d_prev_all, const double* d_next_all, int64_t N,
                          const double* K, int H, double* d_pose, double* d_X) {
@@ -1401,15 +1403,20 @@ static int track_enqueue(slam_ctx* ctx, const double* previous_pose, const doubl
     TrackSetup ts;
     memcpy(ts.K, K, sizeof ts.K);
     memcpy(ts.prev, previous_pose, sizeof ts.prev);  // the first three rows of the 4x4 pose
-    SLAM_TRY(slam_launch(ctx, -1, k_track_setup, dim3(1), dim3(64), 0, ts, tw));
     SLAM_TRY(slam_launch(ctx, -1, k_sample, dim3((H + 63) / 64), dim3(64), 0, (int)SLAM_SAMPLER_CPYTHON,
                          (uint64_t)SLAM_SEED_BASE, (int64_t)0, H, M, 6, (const uint32_t*)ctx->raw.p, ctx->raw_it0,
                          (int32_t*)ctx->idx.p, (int32_t*)ctx->flags.p));
     SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect6, dim3((H + 3) / 4), dim3(64), 0, (const double2*)d_b, d_X3,
-                         (const int32_t*)ctx->idx.p, H, (const double*)tw, hyp));
+                         (const int32_t*)ctx->idx.p, H, ts, tw, hyp));  // also fills the work block tw
     SLAM_TRY(slam_launch(ctx, SLAM_K_TRACK_SCORE, k_track_score, dim3(H), dim3(256), 0, (const double*)tw,
                          (const double*)hyp, (const double2*)d_a, (const double2*)d_b, d_X3, M,
                          (int32_t*)ctx->counts.p, (double*)ctx->errsums.p));
+    if (H <= SLAM_TRACK_FUSED_FINISH_MAX_H) {  // selection and final triangulation in one launch
+        SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_track_finish, dim3((unsigned)std::max<int64_t>(1, (N + 255) / 256)), dim3(256), 0,
+                             (const int32_t*)ctx->counts.p, (const double*)ctx->errsums.p, H, (const double*)hyp, tw, d_pose,
+                             (const double2*)d_prev_all, (const double2*)d_next_all, N, d_X));
+        return SLAM_OK;
+    }
     SLAM_TRY(slam_launch(ctx, -1, k_track_select, dim3(1), dim3(64), 0, (const int32_t*)ctx->counts.p,
                          (const double*)ctx->errsums.p, H, (const double*)hyp, tw, d_pose));
     if (N > 0)

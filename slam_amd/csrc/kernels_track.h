@@ -564,21 +564,25 @@ __global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, 
 // ------------------------------------------------------------------------------------------------
 // K6: score one hypothesis per workgroup   (reference: src/triangulation.py:159-170)
 //   triangulate the M known matches with (K prev_pose[:3], K pose[:3]); count points in front of both cameras;
-//   error = sum of ||X_known - X||.  Fixed summation order: thread-strided partial sums, xor-shuffle tree, 4 waves.
+//   error = sum of ||X_known - X||.  Fixed summation order (a function of M only): thread-strided partial sums,
+//   xor-shuffle tree, the waves in order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_track_score(const double* __restrict__ tw, const double* __restrict__ hyp,
-                                                     const double2* __restrict__ a, const double2* __restrict__ b,
-                                                     const double* __restrict__ X3, int M, int32_t* __restrict__ counts,
-                                                     double* __restrict__ errs) {
-    __shared__ double s_err[4];
-    __shared__ int s_cnt[4];
-    const int tid = threadIdx.x;
+#define SLAM_TRACK_SCORE_MAX_THREADS 512
+__global__ __launch_bounds__(SLAM_TRACK_SCORE_MAX_THREADS) void k_track_score(
+    const double* __restrict__ tw, const double* __restrict__ hyp, const double2* __restrict__ a,
+    const double2* __restrict__ b, const double* __restrict__ X3, int M, int32_t* __restrict__ counts,
+    double* __restrict__ errs) {
+    // The workgroup has as many waves as the M matches fill, eight at most: a thread's triangulations are one
+    // dependent chain each, so the kernel lasts as long as the thread with the most matches.
+    __shared__ double s_err[SLAM_TRACK_SCORE_MAX_THREADS / 64];
+    __shared__ int s_cnt[SLAM_TRACK_SCORE_MAX_THREADS / 64];
+    const int tid = threadIdx.x, T = blockDim.x;
     const double* __restrict__ hp = hyp + (size_t)blockIdx.x * HP_LEN;
     const double tx = hp[HP_T], ty = hp[HP_T + 1], tz = hp[HP_T + 2];
     const double cx = hp[HP_CZ], cy = hp[HP_CZ + 1], cz = hp[HP_CZ + 2];
     double err = 0.0;
     int cnt = 0;
-    for (int i = tid; i < M; i += 256) {
+    for (int i = tid; i < M; i += T) {
         const double2 p = a[i], q = b[i];
         double X[3];
         triangulate_one(tw + TW_P0, hp + HP_P1, p.x, p.y, q.x, q.y, X);
@@ -596,8 +600,11 @@ __global__ __launch_bounds__(256) void k_track_score(const double* __restrict__ 
     if ((tid & 63) == 0) { s_err[tid >> 6] = err; s_cnt[tid >> 6] = cnt; }
     __syncthreads();
     if (tid == 0) {
-        counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        errs[blockIdx.x] = ((s_err[0] + s_err[1]) + s_err[2]) + s_err[3];
+        int c = s_cnt[0];
+        double e = s_err[0];
+        for (int w = 1; w < T / 64; ++w) { c += s_cnt[w]; e += s_err[w]; }
+        counts[blockIdx.x] = c;
+        errs[blockIdx.x] = e;
     }
 }
 

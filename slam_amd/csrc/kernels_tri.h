@@ -46,6 +46,7 @@ __device__ __forceinline__ double rcp_like_division(double x) {
 // coordinates (src/triangulation.py:179), which leaves the two smallest singular values close together and the
 // homogeneous coordinate small - pass SLAM_TRI_ANGLE_TOL_TIGHT.
 #define SLAM_TRI_ANGLE_TOL_TIGHT 1e-15
+template <int MAX_STEPS = SLAM_LEAST4_STEPS>
 __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, const double* __restrict__ P1, double u0,
                                                 double v0, double u1, double v1, double (&X)[3],
                                                 double angle_tol = SLAM_TRI_ANGLE_TOL) {
@@ -68,7 +69,7 @@ __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, c
         for (int j = 0; j < 4; ++j) D[i][j] *= im[j];
     // polished until further rotations would turn y by less than 1e-12 rad (the points are compared to 1e-5)
     double yv[4];
-    least_right_vector_4x4(D, angle_tol, yv);
+    least_right_vector_4x4<MAX_STEPS>(D, angle_tol, yv);
     double Y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Y[i] = m[i] * yv[i];
@@ -165,7 +166,9 @@ __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(c
             asm volatile("" ::: "memory");  // the LDS reads stay inside the loop: hoisted, they cost 40 registers
             const double* cand = s_pw + PW_CAND + 2 * r * PW_CAND_LEN;
             double X[3];
-            triangulate_one(s_pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
+            // (sweeps only: with cameras K [R|t] the warm start is within the tolerance for all but one match in
+            // thousands, and the Newton-like steps would cost the fourth wave per SIMD their registers)
+            triangulate_one<0>(s_pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
             const double tx = cand[PW_CAND_T], ty = cand[PW_CAND_T + 1], tz = cand[PW_CAND_T + 2];
             const double cx = cand[PW_CAND_CZ], cy = cand[PW_CAND_CZ + 1], cz = cand[PW_CAND_CZ + 2];
             const double s2 = (X[0] - tx) * cx + (X[1] - ty) * cy + (X[2] - tz) * cz;

@@ -584,13 +584,20 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
     }
 }
 
-// Right singular vector of the smallest singular value of a 4 x 4 matrix A (held as A[row][col]; destroyed).
+// Right singular vector of the smallest singular value of a 4 x 4 matrix A (held as A[row][col]).
 //
 // Warm start as in rank2_project: G = A^T A; lambda = smallest root of its characteristic quartic by Newton from 0
 // (monotone from below); the largest column of adj(G - lambda I) is parallel to the wanted vector v; a Householder
-// reflector that maps the last unit axis onto v supplies an orthonormal basis with v as its last column.  One-sided Jacobi
-// sweeps on A itself then polish the last column (they do not see G's squared condition number).
+// reflector that maps the last unit axis onto v supplies an orthonormal basis with v as its last column.  The polish
+// works on A itself (it does not see G's squared condition number): Newton-like steps, then one-sided Jacobi sweeps
+// for whatever they leave.  A is not modified.
 // angle_tol: rotation angle below which a pair counts as converged.
+// MAX_STEPS: Newton-like steps a lane may take before the sweeps (0: sweeps only, which keeps 30 registers free where
+// the start is known to be good enough).
+#ifndef SLAM_LEAST4_STEPS
+#define SLAM_LEAST4_STEPS 3
+#endif
+template <int MAX_STEPS = SLAM_LEAST4_STEPS>
 __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double angle_tol, double (&y)[4]) {
     // (the warm start is written with explicit fma: it only has to be good to a few digits)
     double g[4][4];
@@ -659,44 +666,144 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
     const double vi = rsqrt(vn2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = usable ? v[i] * vi : (i == 3 ? 1.0 : 0.0);
-    // Householder reflector H = I - w w^T / (1 + |v_3|) with w = v + sign(v_3) e_3: its last column is -sign(v_3) v and
-    // the other columns complete an orthonormal basis.  w^T w = 2 (1 + |v_3|) >= 2 whatever v_3 is: no cancellation.
-    const double sg = v[3] >= 0.0 ? 1.0 : -1.0;
-    const double w[4] = {v[0], v[1], v[2], v[3] + sg};
-    const double beta = fast_rcp(1.0 + fabs(v[3]));
-    double V[4][4];
+    if constexpr (MAX_STEPS == 0) {
+        // Householder reflector H = I - w w^T / (1 + |v_3|) with w = v + sign(v_3) e_3: its last column is -sign(v_3) v and
+        // the other columns complete an orthonormal basis.  w^T w = 2 (1 + |v_3|) >= 2 whatever v_3 is: no cancellation.
+        const double sg = v[3] >= 0.0 ? 1.0 : -1.0;
+        const double w[4] = {v[0], v[1], v[2], v[3] + sg};
+        const double beta = fast_rcp(1.0 + fabs(v[3]));
+        double V[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) V[i][j] = fma(-beta * w[i], w[j], (i == j) ? 1.0 : 0.0);
-    // B = A H = A - beta (A w) w^T
+            for (int j = 0; j < 4; ++j) V[i][j] = fma(-beta * w[i], w[j], (i == j) ? 1.0 : 0.0);
+        // B = A H = A - beta (A w) w^T
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double aw = beta * fma(A[r][0], w[0], fma(A[r][1], w[1], fma(A[r][2], w[2], A[r][3] * w[3])));
+        for (int r = 0; r < 4; ++r) {
+            const double aw = beta * fma(A[r][0], w[0], fma(A[r][1], w[1], fma(A[r][2], w[2], A[r][3] * w[3])));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) A[r][j] = fma(-aw, w[j], A[r][j]);
+            for (int j = 0; j < 4; ++j) A[r][j] = fma(-aw, w[j], A[r][j]);
+        }
+        jacobi_sweeps<4, 4, true>(A, V, 30, angle_tol, !usable);
+        double n2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n2[j] = fma(A[0][j], A[0][j], fma(A[1][j], A[1][j], fma(A[2][j], A[2][j], A[3][j] * A[3][j])));
+        // a converged least column cannot be longer than any other column (||A v|| >= sigma_min for unit v); if it is,
+        // the start was poor: converge every pair and take the shortest column
+        if (__any(n2[3] > n2[0] || n2[3] > n2[1] || n2[3] > n2[2] || !usable)) {
+            jacobi_sweeps<4, 4, false>(A, V, 30, angle_tol);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) n2[j] = A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j] + A[3][j] * A[3][j];
+        }
+        int least = 3;
+        double best = n2[3];
+#pragma unroll
+        for (int j = 2; j >= 0; --j) {
+            const bool lt = n2[j] < best;
+            best = lt ? n2[j] : best;
+            least = lt ? j : least;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = least == 0 ? V[i][0] : (least == 1 ? V[i][1] : (least == 2 ? V[i][2] : V[i][3]));
+        return;
+    } else {
+        // Polish on A itself.  A Householder reflector H = I - w w^T / (1 + |v_3|) with w = v + sign(v_3) e_3 has
+        // -sign(v_3) v as its last column and completes it to an orthonormal basis (w^T w = 2 (1 + |v_3|) >= 2 whatever
+        // v_3 is: no cancellation).  With b_j the columns of B = A H, c_j = b_j . b_3 and a_j = |b_j|^2, the last column is
+        // done when every pair (j, 3) passes the test of the Jacobi sweeps (|c_j| <= angle_tol |a_j - a_3|, or orthogonal
+        // to rounding).  A lane that is not done takes a Newton-like step: z = (t, 1) with (M0 - a_3 I) t = -m, where
+        // M0 = [b_i . b_j] (i, j < 3) and m = (c_0, c_1, c_2), is the least right singular vector of B up to
+        // |(M0 - a_3 I)^-1| |m| |t|^2: the error is cubed.  v becomes H z, normalised, and the basis is rebuilt from it (B
+        // comes from the untouched A every time, so nothing accumulates).  A sweep of rotations only squares the error
+        // and costs three times the instructions.  Lanes that are done keep their v bit for bit, so a lane's result does
+        // not depend on its wave mates.  What is not done after MAX_STEPS steps - singular values too close for
+        // the step to make sense, or no usable start - goes through the sweeps, starting from the basis reached.
+        double B[4][4], w[4], beta, n2[4];
+        bool done = false, stuck = false;
+#pragma unroll 1
+        for (int step = 0;; ++step) {
+            const double sg = v[3] >= 0.0 ? 1.0 : -1.0;
+            w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3] + sg;
+            beta = fast_rcp(1.0 + fabs(v[3]));
+            // B = A H = A - beta (A w) w^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double aw = beta * fma(A[r][0], w[0], fma(A[r][1], w[1], fma(A[r][2], w[2], A[r][3] * w[3])));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) B[r][j] = fma(-aw, w[j], A[r][j]);
+            }
+            double c[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) n2[j] = fma(B[0][j], B[0][j], fma(B[1][j], B[1][j], fma(B[2][j], B[2][j], B[3][j] * B[3][j])));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c[j] = fma(B[0][j], B[0][3], fma(B[1][j], B[1][3], fma(B[2][j], B[2][3], B[3][j] * B[3][3])));
+            const double floor2 = ((n2[0] + n2[1]) + (n2[2] + n2[3])) * 1e-32;
+            bool need = false;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                need = need || ((n2[j] > floor2) && (n2[3] > floor2) && (c[j] * c[j] > 1e-30 * (n2[j] * n2[3])) &&
+                                (fabs(c[j]) > angle_tol * fabs(n2[j] - n2[3])));
+            done = usable && !need;
+            bool step_now = usable && need && !stuck && step < MAX_STEPS;
+            if (!__any(step_now)) break;
+            const double m01 = fma(B[0][0], B[0][1], fma(B[1][0], B[1][1], fma(B[2][0], B[2][1], B[3][0] * B[3][1])));
+            const double m02 = fma(B[0][0], B[0][2], fma(B[1][0], B[1][2], fma(B[2][0], B[2][2], B[3][0] * B[3][2])));
+            const double m12 = fma(B[0][1], B[0][2], fma(B[1][1], B[1][2], fma(B[2][1], B[2][2], B[3][1] * B[3][2])));
+            const double s00 = n2[0] - n2[3], s11 = n2[1] - n2[3], s22 = n2[2] - n2[3];
+            const double q00 = fma(s11, s22, -m12 * m12), q01 = fma(m02, m12, -m01 * s22), q02 = fma(m01, m12, -m02 * s11);
+            const double q11 = fma(s00, s22, -m02 * m02), q12 = fma(m01, m02, -s00 * m12), q22 = fma(s00, s11, -m01 * m01);
+            const double det = fma(s00, q00, fma(m01, q01, m02 * q02));
+            const double ninv = -fast_rcp(det);
+            const double t0 = ninv * fma(q00, c[0], fma(q01, c[1], q02 * c[2]));
+            const double t1 = ninv * fma(q01, c[0], fma(q11, c[1], q12 * c[2]));
+            const double t2 = ninv * fma(q02, c[0], fma(q12, c[1], q22 * c[2]));
+            const double tt = fma(t0, t0, fma(t1, t1, t2 * t2));
+            stuck = stuck || !(tt <= 0.25);  // (true for NaN too) such a lane waits for the sweeps
+            step_now = step_now && !stuck;
+            // H z with z = (t, 1): z - beta (w . z) w, then to unit length
+            const double wz = beta * fma(w[0], t0, fma(w[1], t1, fma(w[2], t2, w[3])));
+            const double y0 = fma(-wz, w[0], t0), y1 = fma(-wz, w[1], t1), y2 = fma(-wz, w[2], t2), y3 = fma(-wz, w[3], 1.0);
+            const double yi = rsqrt(fma(y0, y0, fma(y1, y1, fma(y2, y2, y3 * y3))));
+            v[0] = step_now ? y0 * yi : v[0];
+            v[1] = step_now ? y1 * yi : v[1];
+            v[2] = step_now ? y2 * yi : v[2];
+            v[3] = step_now ? y3 * yi : v[3];
+        }
+        // a converged least column cannot be longer than any other column (||A v|| >= sigma_min for unit v); if it is, the
+        // start was poor: converge every pair and take the shortest column
+        const bool poor = n2[3] > n2[0] || n2[3] > n2[1] || n2[3] > n2[2];
+        if (__any(!done || poor)) {  // wave-uniform; the rotations leave a lane that is done as it is, bit for bit
+            double V[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) V[i][j] = fma(-beta * w[i], w[j], (i == j) ? 1.0 : 0.0);
+            if (__any(!done)) {
+                jacobi_sweeps<4, 4, true>(B, V, 30, angle_tol, !usable);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n2[j] = fma(B[0][j], B[0][j], fma(B[1][j], B[1][j], fma(B[2][j], B[2][j], B[3][j] * B[3][j])));
+            }
+            if (__any(n2[3] > n2[0] || n2[3] > n2[1] || n2[3] > n2[2] || !usable)) {
+                jacobi_sweeps<4, 4, false>(B, V, 30, angle_tol);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n2[j] = B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j] + B[3][j] * B[3][j];
+            }
+            int least = 3;
+            double best = n2[3];
+#pragma unroll
+            for (int j = 2; j >= 0; --j) {
+                const bool lt = n2[j] < best;
+                best = lt ? n2[j] : best;
+                least = lt ? j : least;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = least == 0 ? V[i][0] : (least == 1 ? V[i][1] : (least == 2 ? V[i][2] : V[i][3]));
+            return;
+        }
+        // every lane of the wave is done: the last column of H (the expression the branch above has for it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = fma(-beta * w[i], w[3], (i == 3) ? 1.0 : 0.0);
     }
-    jacobi_sweeps<4, 4, true>(A, V, 30, angle_tol, !usable);
-    double n2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) n2[j] = fma(A[0][j], A[0][j], fma(A[1][j], A[1][j], fma(A[2][j], A[2][j], A[3][j] * A[3][j])));
-    // a converged least column cannot be longer than any other column (||A v|| >= sigma_min for unit v); if it is,
-    // the start was poor: converge every pair and take the shortest column
-    if (__any(n2[3] > n2[0] || n2[3] > n2[1] || n2[3] > n2[2] || !usable)) {
-        jacobi_sweeps<4, 4, false>(A, V, 30, angle_tol);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) n2[j] = A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j] + A[3][j] * A[3][j];
-    }
-    int least = 3;
-    double best = n2[3];
-#pragma unroll
-    for (int j = 2; j >= 0; --j) {
-        const bool lt = n2[j] < best;
-        best = lt ? n2[j] : best;
-        least = lt ? j : least;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = least == 0 ? V[i][0] : (least == 1 ? V[i][1] : (least == 2 ? V[i][2] : V[i][3]));
 }
 
 // Sum over the 64 lanes of a wave in a fixed order, without LDS traffic: xor-1 and xor-2 inside quads, then the

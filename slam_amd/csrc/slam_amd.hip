@@ -1408,7 +1408,8 @@ static int track_enqueue(slam_ctx* ctx, const double* previous_pose, const doubl
                          (int32_t*)ctx->idx.p, (int32_t*)ctx->flags.p));
     SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect6, dim3((H + 3) / 4), dim3(64), 0, (const double2*)d_b, d_X3,
                          (const int32_t*)ctx->idx.p, H, ts, tw, hyp));  // also fills the work block tw
-    SLAM_TRY(slam_launch(ctx, SLAM_K_TRACK_SCORE, k_track_score, dim3(H), dim3(256), 0, (const double*)tw,
+    const int score_threads = std::min(SLAM_TRACK_SCORE_MAX_THREADS, std::max(64, (M + 63) / 64 * 64));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_TRACK_SCORE, k_track_score, dim3(H), dim3(score_threads), 0, (const double*)tw,
                          (const double*)hyp, (const double2*)d_a, (const double2*)d_b, d_X3, M,
                          (int32_t*)ctx->counts.p, (double*)ctx->errsums.p));
     if (H <= SLAM_TRACK_FUSED_FINISH_MAX_H) {  // selection and final triangulation in one launch

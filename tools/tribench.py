@@ -13,11 +13,12 @@ from slam_amd import _lib, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("-n", type=int, default=1 << 22)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--outliers", type=float, default=0.0, help="fraction of wrong matches in the tiled set")
 a = ap.parse_args()
 ctx = _lib.default_context()
 lib = ctx.lib
 dev = torch.device("cuda", ctx.device)
-big = synth.make_pair(1 << 16, 0.0, seed=5)
+big = synth.make_pair(1 << 16, a.outliers, seed=5)
 reps = a.n // (1 << 16)
 p0 = torch.from_numpy(big["pts0"]).to(dev).repeat(reps, 1).contiguous()
 p1 = torch.from_numpy(big["pts1"]).to(dev).repeat(reps, 1).contiguous()

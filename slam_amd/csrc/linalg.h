@@ -672,20 +672,37 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
         const double sg = v[3] >= 0.0 ? 1.0 : -1.0;
         const double w[4] = {v[0], v[1], v[2], v[3] + sg};
         const double beta = fast_rcp(1.0 + fabs(v[3]));
-        double V[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) V[i][j] = fma(-beta * w[i], w[j], (i == j) ? 1.0 : 0.0);
-        // B = A H = A - beta (A w) w^T
+        // B = A H = A - beta (A w) w^T, in place
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double aw = beta * fma(A[r][0], w[0], fma(A[r][1], w[1], fma(A[r][2], w[2], A[r][3] * w[3])));
 #pragma unroll
             for (int j = 0; j < 4; ++j) A[r][j] = fma(-aw, w[j], A[r][j]);
         }
+        // the test of the sweeps on the three pairs with the last column, and the safety net's test (below): a wave
+        // whose lanes all pass has the last column of H as its answer and forms neither V nor a rotation
+        double n2[4], c[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n2[j] = fma(A[0][j], A[0][j], fma(A[1][j], A[1][j], fma(A[2][j], A[2][j], A[3][j] * A[3][j])));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[j] = fma(A[0][j], A[0][3], fma(A[1][j], A[1][3], fma(A[2][j], A[2][3], A[3][j] * A[3][3])));
+        const double floor2 = ((n2[0] + n2[1]) + (n2[2] + n2[3])) * 1e-32;
+        bool need = !usable || n2[3] > n2[0] || n2[3] > n2[1] || n2[3] > n2[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            need = need || ((n2[j] > floor2) && (n2[3] > floor2) && (c[j] * c[j] > 1e-30 * (n2[j] * n2[3])) &&
+                            (fabs(c[j]) > angle_tol * fabs(n2[j] - n2[3])));
+        if (!__any(need)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = fma(-beta * w[i], w[3], (i == 3) ? 1.0 : 0.0);
+            return;
+        }
+        double V[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) V[i][j] = fma(-beta * w[i], w[j], (i == j) ? 1.0 : 0.0);
         jacobi_sweeps<4, 4, true>(A, V, 30, angle_tol, !usable);
-        double n2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) n2[j] = fma(A[0][j], A[0][j], fma(A[1][j], A[1][j], fma(A[2][j], A[2][j], A[3][j] * A[3][j])));
         // a converged least column cannot be longer than any other column (||A v|| >= sigma_min for unit v); if it is,

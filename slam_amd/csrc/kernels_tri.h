@@ -125,21 +125,26 @@ __global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* _
 //   in front of camera 1: X_z > 0 ; in front of camera 2: (X - t) . (R e_z) > 0 ; count points passing both.
 // The points go to two planes X4[r][N][3], r = 0, 1: plane r holds candidate 2 r, and candidate 2 r + 1 is its negative.
 // counts4 (int64) must be zero on entry.
-// A workgroup is ONE wave and takes 256 consecutive matches, 64 at a time.  The Jacobi polish makes waves finish a
+// A workgroup is ONE wave and takes per_wg consecutive matches (a multiple of 64), 64 at a time.  The Jacobi polish makes waves finish a
 // match at different times; as four-wave workgroups the early waves' slots stayed empty until the last wave had
-// ended (2.6 of 4 waves per SIMD on average).  The wave adds its four counts with one atomic instruction.
-#define SLAM_TRI4_PER_WG 256
+// ended (2.6 of 4 waves per SIMD on average).  The wave adds its four counts with one atomic instruction: all waves'
+// atomics go to the same four words and complete one after the other (about 13 ns each), so per_wg grows with the
+// number of matches - 64 for a single pair (every wave one batch: the shortest kernel), 1024 for millions of matches
+// (at 256 the 65 536 atomics of 16 M matches were as long as the kernel's arithmetic).
+__host__ __device__ inline int tri4_per_wg(int64_t matches_in_launch) {
+    return matches_in_launch <= (1 << 16) ? 64 : (matches_in_launch <= (1 << 20) ? 256 : 1024);
+}
 #ifndef SLAM_TRI4_WAVES_PER_SIMD
 #define SLAM_TRI4_WAVES_PER_SIMD 4
 #endif
 __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(const double* __restrict__ pw, const double2* __restrict__ p0,
                                                      const double2* __restrict__ p1, int64_t N, double* __restrict__ X4,
                                                      unsigned long long* __restrict__ counts4,
-                                                     const PairArgs* __restrict__ batch) {
+                                                     const PairArgs* __restrict__ batch, int per_wg) {
     if (batch) {
         const PairArgs& a = batch[blockIdx.y];
         pw = a.pw; p0 = a.r0; p1 = a.r1; N = a.N; X4 = a.X4; counts4 = a.counts4;
-        if ((int64_t)blockIdx.x * SLAM_TRI4_PER_WG >= N) return;  // the grid is sized for the largest pair
+        if ((int64_t)blockIdx.x * per_wg >= N) return;  // the grid is sized for the largest pair
     }
     const int lane = threadIdx.x;
     // The cameras and the cheirality vectors of the four candidates are staged in LDS once: read from there they are
@@ -151,9 +156,9 @@ __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(c
     __builtin_amdgcn_wave_barrier();
     int cnt[4] = {0, 0, 0, 0};  // wave-uniform
 #pragma unroll 1
-    for (int k = 0; k < SLAM_TRI4_PER_WG / 64; ++k) {
-        const int64_t i = (int64_t)blockIdx.x * SLAM_TRI4_PER_WG + k * 64 + lane;
-        if ((int64_t)blockIdx.x * SLAM_TRI4_PER_WG + k * 64 >= N) break;  // uniform
+    for (int k = 0; k < per_wg / 64; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * per_wg + k * 64 + lane;
+        if ((int64_t)blockIdx.x * per_wg + k * 64 >= N) break;  // uniform
         const bool live = i < N;
         const double2 a = p0[live ? i : N - 1], b = p1[live ? i : N - 1];
         // Candidates 2 r and 2 r + 1 share the rotation and have opposite translations (pose_prepare): the last column

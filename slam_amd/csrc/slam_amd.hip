@@ -1052,9 +1052,10 @@ extern "C" int slam_triangulate(slam_ctx* ctx, const double* P0, const double* P
 // ================================================================================================
 static int tri4_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int64_t N, unsigned long long* d_counts4) {
     SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)2 * (size_t)N * 3 * sizeof(double)));
-    return slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + SLAM_TRI4_PER_WG - 1) / SLAM_TRI4_PER_WG)), dim3(64), 0,
+    const int per_wg = tri4_per_wg(N);
+    return slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + per_wg - 1) / per_wg)), dim3(64), 0,
                        (const double*)ctx->small.p, (const double2*)d_p0, (const double2*)d_p1, N, (double*)ctx->X4.p,
-                       d_counts4, (const PairArgs*)nullptr);
+                       d_counts4, (const PairArgs*)nullptr, per_wg);
 }
 
 extern "C" int slam_pose_candidates_dev(slam_ctx* ctx, const double* E_host, const double* K_host, const double* d_p0,
@@ -1312,9 +1313,10 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
                          (const double2*)nullptr, (const double2*)nullptr, 0, rcut, (double*)nullptr, (uint8_t*)nullptr, all));
     SLAM_TRY(slam_launch(ctx, -1, k_pair_mid, dim3(1, P), dim3(64), 0, kk, (const double*)nullptr, (double*)nullptr,
                          (unsigned long long*)nullptr, all));
-    SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((maxN + SLAM_TRI4_PER_WG - 1) / SLAM_TRI4_PER_WG), P), dim3(64), 0,
+    const int per_wg = tri4_per_wg(maxN);  // (each pair has counts of its own: the atomics of different pairs do not queue)
+    SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((maxN + per_wg - 1) / per_wg), P), dim3(64), 0,
                          (const double*)nullptr, (const double2*)nullptr, (const double2*)nullptr, (int64_t)0,
-                         (double*)nullptr, (unsigned long long*)nullptr, all));
+                         (double*)nullptr, (unsigned long long*)nullptr, all, per_wg));
     const unsigned eb = (unsigned)std::min<int64_t>(((int64_t)maxN * 3 + 255) / 256, 64);
     SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(eb, P), dim3(256), 0, (const double*)nullptr,
                          (const unsigned long long*)nullptr, (const double*)nullptr, (int64_t)0, (double*)nullptr,

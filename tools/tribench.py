@@ -19,9 +19,9 @@ ctx = _lib.default_context()
 lib = ctx.lib
 dev = torch.device("cuda", ctx.device)
 big = synth.make_pair(1 << 16, a.outliers, seed=5)
-reps = a.n // (1 << 16)
-p0 = torch.from_numpy(big["pts0"]).to(dev).repeat(reps, 1).contiguous()
-p1 = torch.from_numpy(big["pts1"]).to(dev).repeat(reps, 1).contiguous()
+reps = max(1, a.n // (1 << 16))
+p0 = torch.from_numpy(big["pts0"]).to(dev).repeat(reps, 1)[:a.n].contiguous()
+p1 = torch.from_numpy(big["pts1"]).to(dev).repeat(reps, 1)[:a.n].contiguous()
 torch.manual_seed(5)
 p1 += torch.rand_like(p1) * 0.25
 E = np.ascontiguousarray(synth.essential_from_motion(big["R"], big["t"]))

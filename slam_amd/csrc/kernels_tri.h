@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* _
 __host__ __device__ inline int tri4_per_wg(int64_t matches_in_launch) {
     return matches_in_launch <= (1 << 16) ? 64 : (matches_in_launch <= (1 << 20) ? 256 : 1024);
 }
+#ifndef SLAM_TRI4_STEPS
+#define SLAM_TRI4_STEPS 0
+#endif
 #ifndef SLAM_TRI4_WAVES_PER_SIMD
 #define SLAM_TRI4_WAVES_PER_SIMD 4
 #endif
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(c
             double X[3];
             // (sweeps only: with cameras K [R|t] the warm start is within the tolerance for all but one match in
             // thousands, and the Newton-like steps would cost the fourth wave per SIMD their registers)
-            triangulate_one<0>(s_pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
+            triangulate_one<SLAM_TRI4_STEPS>(s_pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
             const double tx = cand[PW_CAND_T], ty = cand[PW_CAND_T + 1], tz = cand[PW_CAND_T + 2];
             const double cx = cand[PW_CAND_CZ], cy = cand[PW_CAND_CZ + 1], cz = cand[PW_CAND_CZ + 2];
             const double s2 = (X[0] - tx) * cx + (X[1] - ty) * cy + (X[2] - tz) * cz;

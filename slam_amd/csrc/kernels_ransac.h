@@ -806,8 +806,9 @@ __device__ __forceinline__ void barrier_lds_only() {
 
 template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
 __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32) / WAVES) void k_ransac(
-    const double2* __restrict__ p0, const double2* __restrict__ p1, int N, const int32_t* __restrict__ idx_in,
-    uint64_t seed, int64_t it0, int H, const uint32_t* __restrict__ raw, int64_t raw_it0, double rcut,
+    // (what the first load of a wave needs comes first: the leading arguments are preloaded into scalar registers)
+    const uint32_t* __restrict__ raw, int64_t raw_it0, int64_t it0, int H, int N, const double2* __restrict__ p0,
+    const double2* __restrict__ p1, const int32_t* __restrict__ idx_in, uint64_t seed, double rcut,
     double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags,
     const PairArgs* __restrict__ batch) {
     if (batch) {

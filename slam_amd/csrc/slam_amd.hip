@@ -430,15 +430,15 @@ static int launch_fused(slam_ctx* ctx, const double2* p0, const double2* p1, int
     if ((H + SLAM_HB - 1) / SLAM_HB <= ctx->num_cus / 2) {
         const dim3 grid((H + 3) / 4);
 #define SLAM_CALL(PPL, WAVES)                                                                                         \
-    return slam_launch(ctx, SLAM_K_SCORE, k_ransac<4, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, p0, p1, N, \
-                       d_idx, seed, it0, H, raw, ctx->raw_it0, thr, F, counts, errsums, flags, (const PairArgs*)nullptr)
+    return slam_launch(ctx, SLAM_K_SCORE, k_ransac<4, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, raw, ctx->raw_it0, \
+                       it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr)
         SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
     }
     const dim3 grid((H + SLAM_HB - 1) / SLAM_HB);
 #define SLAM_CALL(PPL, WAVES)                                                                                         \
-    return slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, p0, p1, N, \
-                       d_idx, seed, it0, H, raw, ctx->raw_it0, thr, F, counts, errsums, flags, (const PairArgs*)nullptr)
+    return slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, raw, ctx->raw_it0, \
+                       it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr)
     SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
 }
@@ -1300,8 +1300,8 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
         const dim3 grid((clsH + SLAM_HB - 1) / SLAM_HB, n_cls);
 #define SLAM_BATCH_RANSAC(PPL)                                                                                            \
     SLAM_TRY(slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, 8, SLAM_SAMPLER_CPYTHON, false>, grid, dim3(512), 0,     \
-                         (const double2*)nullptr, (const double2*)nullptr, 0, (const int32_t*)nullptr,                    \
-                         (uint64_t)SLAM_SEED_BASE, (int64_t)0, 0, (const uint32_t*)ctx->raw.p, ctx->raw_it0, rcut,        \
+                         (const uint32_t*)ctx->raw.p, ctx->raw_it0, (int64_t)0, 0, 0, (const double2*)nullptr,            \
+                         (const double2*)nullptr, (const int32_t*)nullptr, (uint64_t)SLAM_SEED_BASE, rcut,                \
                          (double*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)ctx->flags.p, part))
         if (cls == 0) SLAM_BATCH_RANSAC(1);
         else if (cls == 1) SLAM_BATCH_RANSAC(4);

@@ -502,10 +502,10 @@ __device__ __forceinline__ void resect6_jacobi(double (&a)[12], int c, int base,
 
 // column c of the design matrix of hypothesis hh: rows 2p = [0,0,0,0, -Xh, v Xh], rows 2p+1 = [Xh, 0,0,0,0, -u Xh]
 __device__ __forceinline__ void resect6_column(const double2* __restrict__ uv, const double* __restrict__ X3,
-                                               const int32_t* __restrict__ idx, int hh, int c, double (&a)[12]) {
+                                               const int32_t* idx6, int c, double (&a)[12]) {
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
-        const int i = idx[(size_t)hh * 6 + p];
+        const int i = idx6[p];
         const double2 q = uv[i];
         const int k = c & 3;
         const double xk = k == 3 ? 1.0 : X3[3 * (size_t)i + k];
@@ -538,22 +538,40 @@ __global__ __launch_bounds__(64) void k_track_setup(TrackSetup s, double* __rest
 
 // setup: the kernels after this one read the work block tw; workgroup 0 fills it on the way (this kernel itself takes
 // the intrinsics from the argument), which saves the tracking step a launch.
-__global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, const double* __restrict__ X3,
-                                                const int32_t* __restrict__ idx, int H, TrackSetup setup,
-                                                double* __restrict__ tw, double* __restrict__ hyp) {
+// Sampling: lane 0 of each group draws the group's six indices itself (random.seed(0x1337BEEF + it);
+// random.sample(range(M), 6), src/triangulation.py:151-153, replayed from the iteration's row of the MT19937 table: the
+// lane-sequential form of the sampler, as the sampling kernel has it), which saves the step another launch: the draw
+// costs a fraction of a microsecond here and the front end's four as a kernel of its own.
+__global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, const double* __restrict__ X3, int M,
+                                                const uint32_t* __restrict__ raw, int64_t raw_it0, int H,
+                                                TrackSetup setup, double* __restrict__ tw, double* __restrict__ hyp,
+                                                int32_t* __restrict__ flags) {
     __shared__ double s_R[4][12][16];
+    __shared__ uint8_t s_pool[SLAM_POOL_MAX * 4];
+    __shared__ uint32_t s_words[SLAM_PREFETCH_WORDS * 4];
+    __shared__ int32_t s_idx[4][8];
     const int lane = threadIdx.x;
     if (blockIdx.x == 0) track_setup(setup, tw, lane);
     const int c = lane & 15;                  // column owned by this lane
     const int base = lane & 48;               // first lane of the group
     const int h = blockIdx.x * 4 + (lane >> 4);
     const int hh = h < H ? h : H - 1;
+    if (c == 0) {
+        int32_t out[SLAM_MAX_K];
+        const bool ok = sample_cpython(raw + (size_t)(hh - raw_it0) * SLAM_RAW_WORDS, M, 6, out, s_words, s_pool, lane >> 4, 4);
+#pragma unroll
+        for (int p = 0; p < 6; ++p) s_idx[lane >> 4][p] = min(max(out[p], 0), M - 1);  // never outside the arrays
+        if (!ok) atomicOr(&flags[0], 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double a[12], cam[12];
-    resect6_column(uv, X3, idx, hh, c, a);
+    resect6_column(uv, X3, s_idx[lane >> 4], c, a);
     const bool fine = resect6_block_iteration(a, c, s_R[lane >> 4], cam);
     if (__any(!fine)) {  // wave-uniform; a group that was fine keeps its numbers
         double cam2[12];
-        resect6_column(uv, X3, idx, hh, c, a);
+        resect6_column(uv, X3, s_idx[lane >> 4], c, a);
         resect6_jacobi(a, c, base, cam2);
 #pragma unroll
         for (int i = 0; i < 12; ++i) cam[i] = fine ? cam[i] : cam2[i];

@@ -1396,7 +1396,6 @@ static int track_enqueue(slam_ctx* ctx, const double* previous_pose, const doubl
                          const double* d_X3, int M, const double* d_prev_all, const double* d_next_all, int64_t N,
                          const double* K, int H, double* d_pose, double* d_X) {
     SLAM_TRY(slam_fill_raw_table(ctx, SLAM_SEED_BASE, 0, H));
-    SLAM_TRY(slam_reserve(ctx, ctx->idx, (size_t)H * 8 * sizeof(int32_t)));
     SLAM_TRY(slam_reserve(ctx, ctx->track, ((size_t)TW_LEN + (size_t)H * HP_LEN) * sizeof(double)));
     SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t)));
     SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
@@ -1405,11 +1404,8 @@ static int track_enqueue(slam_ctx* ctx, const double* previous_pose, const doubl
     TrackSetup ts;
     memcpy(ts.K, K, sizeof ts.K);
     memcpy(ts.prev, previous_pose, sizeof ts.prev);  // the first three rows of the 4x4 pose
-    SLAM_TRY(slam_launch(ctx, -1, k_sample, dim3((H + 63) / 64), dim3(64), 0, (int)SLAM_SAMPLER_CPYTHON,
-                         (uint64_t)SLAM_SEED_BASE, (int64_t)0, H, M, 6, (const uint32_t*)ctx->raw.p, ctx->raw_it0,
-                         (int32_t*)ctx->idx.p, (int32_t*)ctx->flags.p));
-    SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect6, dim3((H + 3) / 4), dim3(64), 0, (const double2*)d_b, d_X3,
-                         (const int32_t*)ctx->idx.p, H, ts, tw, hyp));  // also fills the work block tw
+    SLAM_TRY(slam_launch(ctx, SLAM_K_RESECT, k_resect6, dim3((H + 3) / 4), dim3(64), 0, (const double2*)d_b, d_X3, M,
+                         (const uint32_t*)ctx->raw.p, ctx->raw_it0, H, ts, tw, hyp, (int32_t*)ctx->flags.p));  // draws its samples, fills tw
     const int score_threads = std::min(SLAM_TRACK_SCORE_MAX_THREADS, std::max(64, (M + 63) / 64 * 64));
     SLAM_TRY(slam_launch(ctx, SLAM_K_TRACK_SCORE, k_track_score, dim3(H), dim3(score_threads), 0, (const double*)tw,
                          (const double*)hyp, (const double2*)d_a, (const double2*)d_b, d_X3, M,

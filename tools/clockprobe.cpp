@@ -1,7 +1,7 @@
 // Step rate of back-to-back RANSAC bursts over a few seconds, with the shader clock measured between bursts (a
 // one-wave kernel on a stream of its own, started in the middle of a burst, that spins for a fixed number of shader cycles and reads the constant 100 MHz clock around it):
 // shows whether a change of the step rate under sustained load comes with a change of the clock.
-//   clockprobe SECONDS [LANES [pair.bin [under-load]]]
+//   clockprobe SECONDS [LANES [pair.bin|- [under-load]]]
 // build: hipcc --offload-arch=gfx950 -O2 -Iinclude -o tools/_bin/clockprobe tools/clockprobe.cpp -Lslam_amd/lib -lslam_amd -lpthread
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     std::normal_distribution<double> nd(0.0, 1.0);
     std::vector<double> p0(2 * N), p1(2 * N);
     for (int i = 0; i < 2 * N; ++i) { p0[i] = nd(rng); p1[i] = p0[i] + 0.05 * nd(rng); }
-    if (argc > 3) {
+    if (argc > 3 && strcmp(argv[3], "-")) {  // "-": the built-in synthetic pair
         FILE* f = fopen(argv[3], "rb");
         if (!f || fread(p0.data(), 8, 2 * N, f) != (size_t)(2 * N) || fread(p1.data(), 8, 2 * N, f) != (size_t)(2 * N)) return 1;
         fclose(f);

@@ -84,41 +84,57 @@ __global__ __launch_bounds__(1024) void k_match_finish(const uint2* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int q0 = 0; q0 < n0; q0 += 1024) {
-        const int q = q0 + tid;
-        uint32_t k1 = SLAM_MATCH_EMPTY, k2 = SLAM_MATCH_EMPTY;
-        if (q < n0) {
+    // 4096 queries at a time, four per thread (q0 + j * 1024 + tid): the slice loop runs over all four at once, so
+    // that sixteen loads are in flight per thread instead of four (26.4 -> 25.4 us per 4096 x 4096 call; what remains
+    // is the 512 KB of partial keys passing through one CU: 8 k cycles at 64 bytes per cycle).
+    constexpr int QPT = 4;
+    for (int q0 = 0; q0 < n0; q0 += QPT * 1024) {
+        uint32_t k1[QPT], k2[QPT];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) { k1[j] = SLAM_MATCH_EMPTY; k2[j] = SLAM_MATCH_EMPTY; }
 #pragma unroll 4
-            for (int s = 0; s < slices; ++s) {
-                const uint2 k = part[(size_t)s * n0 + q];
-                top2_insert(k.x, k1, k2);
-                top2_insert(k.y, k1, k2);
+        for (int s = 0; s < slices; ++s) {
+            uint2 k[QPT];
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                const int q = q0 + j * 1024 + tid;
+                k[j] = part[(size_t)s * n0 + (q < n0 ? q : n0 - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                top2_insert(k[j].x, k1[j], k2[j]);
+                top2_insert(k[j].y, k1[j], k2[j]);
             }
         }
-        const int i1 = k1 == SLAM_MATCH_EMPTY ? -1 : (int)(k1 & (SLAM_MATCH_MAX_TRAIN - 1));
-        const int d1 = k1 == SLAM_MATCH_EMPTY ? -1 : (int)(k1 >> SLAM_MATCH_INDEX_BITS);
-        const int i2 = k2 == SLAM_MATCH_EMPTY ? -1 : (int)(k2 & (SLAM_MATCH_MAX_TRAIN - 1));
-        const int d2 = k2 == SLAM_MATCH_EMPTY ? -1 : (int)(k2 >> SLAM_MATCH_INDEX_BITS);
-        if (q < n0 && index) { index[2 * (size_t)q] = i1; index[2 * (size_t)q + 1] = i2; }
-        if (q < n0 && distance) { distance[2 * (size_t)q] = d1; distance[2 * (size_t)q + 1] = d2; }
-        const bool keep = q < n0 && i2 >= 0 && 2 * d1 < d2;
-        const unsigned long long b = __ballot(keep);
-        const int before = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wave] = __popcll(b);
-        __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (keep && m0) {
-            m0[off + before] = pts0[q];
-            m1[off + before] = pts1[i1];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int q = q0 + j * 1024 + tid;
+            if (q0 + j * 1024 >= n0) break;  // uniform
+            const int i1 = k1[j] == SLAM_MATCH_EMPTY ? -1 : (int)(k1[j] & (SLAM_MATCH_MAX_TRAIN - 1));
+            const int d1 = k1[j] == SLAM_MATCH_EMPTY ? -1 : (int)(k1[j] >> SLAM_MATCH_INDEX_BITS);
+            const int i2 = k2[j] == SLAM_MATCH_EMPTY ? -1 : (int)(k2[j] & (SLAM_MATCH_MAX_TRAIN - 1));
+            const int d2 = k2[j] == SLAM_MATCH_EMPTY ? -1 : (int)(k2[j] >> SLAM_MATCH_INDEX_BITS);
+            if (q < n0 && index) { index[2 * (size_t)q] = i1; index[2 * (size_t)q + 1] = i2; }
+            if (q < n0 && distance) { distance[2 * (size_t)q] = d1; distance[2 * (size_t)q + 1] = d2; }
+            const bool keep = q < n0 && i2 >= 0 && 2 * d1 < d2;
+            const unsigned long long b = __ballot(keep);
+            const int before = __popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wave] = __popcll(b);
+            __syncthreads();
+            int off = s_base;
+            for (int w = 0; w < wave; ++w) off += s_wave[w];
+            if (keep && m0) {
+                m0[off + before] = pts0[q];
+                m1[off + before] = pts1[i1];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int w = 0; w < 16; ++w) tot += s_wave[w];
+                s_base += tot;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += s_wave[w];
-            s_base += tot;
-        }
-        __syncthreads();
     }
     if (tid == 0) *n_matched = s_base;
 }

@@ -391,33 +391,47 @@ __global__ __launch_bounds__(256) void k_emit_points(const double* __restrict__ 
 //   avg = mean(p); s = mean(||p - avg||) / sqrt(2); out = (p - avg)/s; T = [[s,0,-s ax],[0,s,-s ay],[0,0,1]]
 // Single workgroup, fixed-order reductions.
 // ------------------------------------------------------------------------------------------------
+// Sum over the 1024 threads of a workgroup, the same on every thread: butterfly inside the wave (wave_sum_f64: the
+// operands of every addition are those of an xor-shuffle butterfly, so the bits are too), then the 16 wave totals in
+// order.  Every call needs 16 doubles of LDS of its own (s_red), so that no barrier has to protect their reuse.
 __device__ __forceinline__ double block_sum_1024(double v, double* s_red) {
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    __syncthreads();
+    v = wave_sum_f64(v);
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
     double t = 0.0;
     for (int w = 0; w < 16; ++w) t += s_red[w];
     return t;
 }
+// two sums behind one barrier
+__device__ __forceinline__ void block_sum2_1024(double& a, double& b, double* s_red_a, double* s_red_b) {
+    const int tid = threadIdx.x;
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    if ((tid & 63) == 0) { s_red_a[tid >> 6] = a; s_red_b[tid >> 6] = b; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < 16; ++w) { ta += s_red_a[w]; tb += s_red_b[w]; }
+    a = ta;
+    b = tb;
+}
 
 __global__ __launch_bounds__(1024) void k_normalize(const double2* __restrict__ p, int N, double2* __restrict__ out,
                                                     double* __restrict__ T) {
-    __shared__ double s_red[16];
+    __shared__ double s_red[3][16];
     const int tid = threadIdx.x;
     double sx = 0.0, sy = 0.0;
     for (int i = tid; i < N; i += 1024) { const double2 v = p[i]; sx += v.x; sy += v.y; }
-    const double ax = block_sum_1024(sx, s_red) / (double)N;
-    const double ay = block_sum_1024(sy, s_red) / (double)N;
+    block_sum2_1024(sx, sy, s_red[0], s_red[1]);
+    const double ax = sx / (double)N;
+    const double ay = sy / (double)N;
     double sd = 0.0;
     for (int i = tid; i < N; i += 1024) {
         const double2 v = p[i];
         const double dx = v.x - ax, dy = v.y - ay;
         sd += sqrt(dx * dx + dy * dy);
     }
-    const double s = (block_sum_1024(sd, s_red) / (double)N) / sqrt(2.0);
+    const double s = (block_sum_1024(sd, s_red[2]) / (double)N) / sqrt(2.0);
     for (int i = tid; i < N; i += 1024) {
         const double2 v = p[i];
         out[i] = make_double2((v.x - ax) / s, (v.y - ay) / s);
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(1024) void k_normalize_pair(const double2* __restri
                                                          int N, double2* __restrict__ outa, double2* __restrict__ outb,
                                                          double* __restrict__ Ta, double* __restrict__ Tb,
                                                          const PairArgs* __restrict__ batch) {
-    __shared__ double s_red[16];
+    __shared__ double s_red[3][16];
     if (batch) {
         const PairArgs& a = batch[blockIdx.y];
         pa = a.r0; pb = a.r1; N = a.N; outa = a.n0; outb = a.n1; Ta = a.pw + PW_T0; Tb = a.pw + PW_T1;
@@ -446,15 +460,16 @@ __global__ __launch_bounds__(1024) void k_normalize_pair(const double2* __restri
     const int tid = threadIdx.x;
     double sx = 0.0, sy = 0.0;
     for (int i = tid; i < N; i += 1024) { const double2 v = p[i]; sx += v.x; sy += v.y; }
-    const double ax = block_sum_1024(sx, s_red) / (double)N;
-    const double ay = block_sum_1024(sy, s_red) / (double)N;
+    block_sum2_1024(sx, sy, s_red[0], s_red[1]);
+    const double ax = sx / (double)N;
+    const double ay = sy / (double)N;
     double sd = 0.0;
     for (int i = tid; i < N; i += 1024) {
         const double2 v = p[i];
         const double dx = v.x - ax, dy = v.y - ay;
         sd += sqrt(dx * dx + dy * dy);
     }
-    const double s = (block_sum_1024(sd, s_red) / (double)N) / sqrt(2.0);
+    const double s = (block_sum_1024(sd, s_red[2]) / (double)N) / sqrt(2.0);
     for (int i = tid; i < N; i += 1024) {
         const double2 v = p[i];
         out[i] = make_double2((v.x - ax) / s, (v.y - ay) / s);

@@ -52,3 +52,23 @@ def test_returned_point_is_the_least_singular_direction(kind):
     excess = (res[ok] - sigma[ok, 3]) / sigma[ok, 0]
     print(f"{kind}: largest excess of |D' y| over the smallest singular value, relative to the largest: {excess.max():.2e}")
     assert excess.max() < 1e-12
+
+
+def test_pose_recovery_does_not_depend_on_the_launch_shape():
+    """The pose recovery kernel takes 64, 256 or 1024 matches per workgroup depending on how many there are (its
+    count atomics queue on four words).  A match's point must not depend on that: the first n matches of a list give
+    the same points, bit for bit, whether the list ends there or goes on across a shape boundary, and the cheirality
+    counts of the longer list are those of the shorter one plus the extra matches' own."""
+    from slam_amd import epipolar, synth
+    base = synth.make_pair(1 << 16, 0.1, seed=31)
+    E = synth.essential_from_motion(base["R"], base["t"])
+    K = base["K"]
+    reps = 17
+    p0 = np.tile(base["pts0"], (reps, 1))
+    p1 = np.tile(base["pts1"], (reps, 1)) + np.random.default_rng(32).uniform(0, 0.25, (reps << 16, 2))
+    sizes = [4096, (1 << 16), (1 << 16) + 1, (1 << 20) - 37, (1 << 20), (1 << 20) + 1, reps << 16]
+    ref_pose, ref_X = epipolar.calculate_pose_from_essential_matrix(E, p0[:sizes[-1]], p1[:sizes[-1]], K)
+    for n in sizes[:-1]:
+        pose, X = epipolar.calculate_pose_from_essential_matrix(E, p0[:n], p1[:n], K)
+        assert np.array_equal(pose, ref_pose), n      # (the winner is the same for every prefix of this list)
+        assert np.array_equal(X, ref_X[:n], equal_nan=True), n

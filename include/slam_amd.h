@@ -121,7 +121,10 @@ int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int
  *  - with d_idx == NULL and SLAM_SAMPLER_CPYTHON the context's MT19937 word table must already cover
  *    [it0, it0 + H) for this seed (any earlier call with that seed and range made it); otherwise SLAM_EINVAL.
  *    Pre-drawn indices and the counter-based sampler need no table;
- *  - always on the context's ordered stream (slam_set_concurrency does not apply).
+ *  - always on the context's ordered stream (slam_set_concurrency does not apply);
+ *  - more than 4096 hypotheses on more than 4096 matches are scored by the fused kernel in ranges of 4096 hypotheses
+ *    (the per-chunk partial tables of the usual large-H path are a buffer that grows): same bits, but every workgroup
+ *    reads all matches, so this corner is slower than slam_ransac_f_dev.
  * Every call on one GPU shares that GPU's array, from whatever context: calls that overlap on one GPU (two contexts,
  * or two streams set with slam_set_stream) race.  Results are bit-identical to slam_ransac_f_dev's. */
 #define SLAM_NOALLOC_MAX_H 16384

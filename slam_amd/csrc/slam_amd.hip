@@ -497,8 +497,24 @@ static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int
 
 template <int SAMPLER>
 static int launch_ransac(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
-                         int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
+                         int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums,
+                         bool no_partial_tables) {
     const bool fused = H <= SLAM_FUSED_MAX_H;
+    if (!fused && no_partial_tables && N > 512 * 8) {
+        // The split path would need per-chunk partial tables (a context buffer that grows on demand).  The fused
+        // kernel walks the chunks itself, in the same order: ranges of SLAM_FUSED_MAX_H hypotheses, same bits.
+        for (int t0 = 0; t0 < H; t0 += SLAM_FUSED_MAX_H) {
+            const int Ht = std::min(SLAM_FUSED_MAX_H, H - t0);
+            const int32_t* idx_t = d_idx ? d_idx + (size_t)t0 * 8 : nullptr;
+            if (ctx->sampson)
+                SLAM_TRY((launch_fused<SAMPLER, true>(ctx, p0, p1, N, idx_t, seed, it0 + t0, Ht, thr, F + (size_t)t0 * 9,
+                                                      counts + t0, errsums + t0)));
+            else
+                SLAM_TRY((launch_fused<SAMPLER, false>(ctx, p0, p1, N, idx_t, seed, it0 + t0, Ht, thr, F + (size_t)t0 * 9,
+                                                       counts + t0, errsums + t0)));
+        }
+        return SLAM_OK;
+    }
     if (ctx->sampson)
         return fused ? launch_fused<SAMPLER, true>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums)
                      : launch_split<SAMPLER, true>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
@@ -515,7 +531,8 @@ static dim3 select_grid(int N, const void* mask) {
 
 static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                           int sampler, uint64_t seed, int64_t it0, int H, double thr, double* d_record,
-                          uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all) {
+                          uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all,
+                          bool no_alloc = false) {
     SLAM_REQUIRE(ctx, d_p0 && d_p1 && d_record, "points or record pointer is NULL");
     SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");          // reference: src/epipolar.py:60
     SLAM_REQUIRE(ctx, N <= SLAM_MAX_MATCHES, "more than 2^27 matches");  // the kernels address matches by 32-bit byte offsets
@@ -530,12 +547,12 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     const double2* p1 = (const double2*)d_p1;
     if (!ctx->sampson) thr = square_cutoff(thr);  // algebraic mode: from here on the threshold is the cutoff on |r|
     if (d_idx) {
-        SLAM_TRY(launch_ransac<-1>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
+        SLAM_TRY(launch_ransac<-1>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, d_F_all, d_counts, d_errsums, no_alloc));
     } else if (sampler == SLAM_SAMPLER_CPYTHON) {
-        SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));
-        SLAM_TRY(launch_ransac<SLAM_SAMPLER_CPYTHON>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
+        if (!no_alloc) SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));  // (the caller has checked that the table covers the range)
+        SLAM_TRY(launch_ransac<SLAM_SAMPLER_CPYTHON>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums, no_alloc));
     } else {
-        SLAM_TRY(launch_ransac<SLAM_SAMPLER_COUNTER>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums));
+        SLAM_TRY(launch_ransac<SLAM_SAMPLER_COUNTER>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_errsums, no_alloc));
     }
     // large H: a first stage reduces ranges of SLAM_SELECT_SPAN hypotheses in parallel
     const int32_t* sel_counts = d_counts;
@@ -623,7 +640,7 @@ extern "C" int slam_ransac_f_dev_noalloc(slam_ctx* ctx, const double* d_p0, cons
     ctx->profiling = false;  // the timing helper may synchronise when its event pool wraps
     ctx->cur = ctx->stream;
     const int rc = ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
-                                  d_errsums, d_F_all);
+                                  d_errsums, d_F_all, /*no_alloc=*/true);
     ctx->profiling = prof;
     return rc;
 }

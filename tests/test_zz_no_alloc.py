@@ -59,6 +59,42 @@ def test_noalloc_entry_point_equals_the_allocating_one():
     assert np.array_equal(r_a, r_b) and np.array_equal(m_a, m_b)
 
 
+def test_noalloc_entry_point_with_several_chunks_of_matches_and_many_hypotheses():
+    """More than 4096 matches AND more than 4096 hypotheses: the allocating call scores through per-chunk partial
+    tables in a context buffer; the other form must get by without them (it runs the fused kernel over ranges of 4096
+    hypotheses) and still return the same bits.  A fresh context, the non-allocating call first: the device's free
+    memory does not change across it."""
+    import torch
+    ctx = _lib.Context(0)
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    N, H = 300000, 4200   # 74 chunks: the partial tables of the allocating call take 3.7 MB
+    p0, p1 = _pair_on_device(torch, dev, N, 44)
+    rec = torch.full((_lib.REC_LEN,), -7.0, dtype=torch.float64, device=dev)
+    mask = torch.full((N,), 9, dtype=torch.uint8, device=dev)
+    want_rec, want_mask = torch.empty_like(rec), torch.empty_like(mask)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    ctx.check(lib.slam_ransac_f_dev_noalloc(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 7, 0, H,
+                                            0.005, rec.data_ptr(), mask.data_ptr()))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    assert torch.cuda.mem_get_info(dev)[0] == free_before
+    ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 7, 0, H, 0.005,
+                                    want_rec.data_ptr(), want_mask.data_ptr(), None, None, None))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    assert torch.equal(rec, want_rec) and torch.equal(mask, want_mask)
+    assert rec[_lib.REC_COUNT].item() == mask.sum().item() and rec[_lib.REC_COUNT].item() >= 8
+    # pre-drawn indices take the same route (the ranges read their own part of the index table)
+    idx = np.empty((H, 8), dtype=np.int32)
+    ctx.check(lib.slam_sample_indices(ctx.handle, _lib.SAMPLER_COUNTER, 7, 0, H, N, 8, _lib.ptr(idx)))
+    d_idx = torch.from_numpy(idx).to(dev)
+    rec.fill_(-7.0)
+    ctx.check(lib.slam_ransac_f_dev_noalloc(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, d_idx.data_ptr(), _lib.SAMPLER_COUNTER, 7,
+                                            0, H, 0.005, rec.data_ptr(), mask.data_ptr()))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    assert torch.equal(rec, want_rec) and torch.equal(mask, want_mask)
+
+
 def test_noalloc_entry_point_rejects_what_it_cannot_do():
     import torch
     ctx = _lib.default_context()

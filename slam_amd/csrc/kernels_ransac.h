@@ -504,20 +504,37 @@ __device__ __forceinline__ double residual(double a0, double a1, double b0, doub
 // alone accumulate r*r: no select instructions, and no scalar instruction between the compare and the accumulation.
 // The population count of the scalar copy is the inlier count (one scalar instruction, kept here so that the mask
 // does not have to stay alive).
-__device__ __forceinline__ int accumulate_inliers(double r, double rcut, unsigned long long live,
-                                                  unsigned long long full_exec, double& es) {
+// COUNT_IN_ASM: the running count is added inside the statement, on the scalar unit.  The fused kernel wants that:
+// left to the compiler, the 64 population counts of a chunk stay in scalar registers and are summed by vector
+// instructions after the loop, on the way to LDS - 64 instructions between the end of the loop and the barrier.
+template <bool COUNT_IN_ASM>
+__device__ __forceinline__ void accumulate_inliers(double r, double rcut, unsigned long long live,
+                                                   unsigned long long full_exec, double& es, int& count) {
     unsigned long long lt_mask;
     int n;
-    asm volatile(
-        "s_mov_b64 exec, %[live]\n\t"
-        "v_cmpx_lt_f64_e64 %[lt], |%[r]|, %[rc]\n\t"
-        "v_fma_f64 %[es], %[r], %[r], %[es]\n\t"
-        "s_mov_b64 exec, %[full]\n\t"
-        "s_bcnt1_i32_b64 %[n], %[lt]"
-        : [es] "+v"(es), [lt] "=&s"(lt_mask), [n] "=&s"(n)  // written before the inputs are all read
-        : [r] "v"(r), [rc] "s"(rcut), [live] "s"(live), [full] "s"(full_exec)
-        : "scc");
-    return n;
+    if (COUNT_IN_ASM) {
+        asm volatile(
+            "s_mov_b64 exec, %[live]\n\t"
+            "v_cmpx_lt_f64_e64 %[lt], |%[r]|, %[rc]\n\t"
+            "v_fma_f64 %[es], %[r], %[r], %[es]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "s_bcnt1_i32_b64 %[n], %[lt]\n\t"
+            "s_add_i32 %[c], %[c], %[n]"
+            : [es] "+v"(es), [lt] "=&s"(lt_mask), [n] "=&s"(n), [c] "+s"(count)  // written before the inputs are all read
+            : [r] "v"(r), [rc] "s"(rcut), [live] "s"(live), [full] "s"(full_exec)
+            : "scc");
+    } else {
+        asm volatile(
+            "s_mov_b64 exec, %[live]\n\t"
+            "v_cmpx_lt_f64_e64 %[lt], |%[r]|, %[rc]\n\t"
+            "v_fma_f64 %[es], %[r], %[r], %[es]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "s_bcnt1_i32_b64 %[n], %[lt]"
+            : [es] "+v"(es), [lt] "=&s"(lt_mask), [n] "=&s"(n)  // written before the inputs are all read
+            : [r] "v"(r), [rc] "s"(rcut), [live] "s"(live), [full] "s"(full_exec)
+            : "scc");
+        count += n;
+    }
 }
 
 // Sampson mode: r is the distance itself, added as it is
@@ -581,17 +598,28 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
             asm volatile("" ::: "memory");  // later hypotheses' F loads stay below: hoisting all of them costs 144 registers
             // The two waves of a SIMD issue oldest first; left alone, the older wave runs at the rate of a wave that
             // has the SIMD to itself and the younger one finishes its last third alone, at that same (slower) rate.
-            // The wave that is behind gets the higher priority, so both stay within two hypotheses of each other.
-            if (j < HB / 4) __builtin_amdgcn_s_setprio(3);       // (the loop is unrolled: one of these remains per turn)
-            else if (j < HB / 2) __builtin_amdgcn_s_setprio(2);
-            else if (j < 3 * HB / 4) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
+            // The wave that is behind gets the higher priority (set in the loop below, by progress).
             double es = 0.0;
             cnt[j] = 0;
             // two matches at a time: both residuals first (independent chains), then the masked accumulations in order
             constexpr int KB = PPL >= 2 ? 2 : 1;
 #pragma unroll
             for (int k0 = 0; k0 < PPL; k0 += KB) {
+                {   // Priority by progress q of STEPS.  A wave with priority gains on the other one slowly (it cannot
+                    // use every issue slot), and what matters is how far apart the two are at the END, so the levels
+                    // get shorter towards it: the first half of the loop, then 5/16, 1/8 and the last 1/16 of it
+                    // (four equal levels left the younger wave 1 000 cycles behind at N=4096, these 500).
+                    constexpr int STEPS = HB * PPL / KB;
+                    constexpr int L0 = STEPS / 16 > 0 ? STEPS / 16 : 1, L1 = L0 + (STEPS / 8 > 0 ? STEPS / 8 : 1), L2 = STEPS / 2;
+                    const int q = j * (PPL / KB) + k0 / KB;
+                    auto level = [](int qq) { return qq >= STEPS - L0 ? 0 : (qq >= STEPS - L1 ? 1 : (qq >= STEPS - L2 ? 2 : 3)); };
+                    if (q == 0 || level(q) != level(q - 1)) {
+                        if (level(q) == 3) __builtin_amdgcn_s_setprio(3);
+                        else if (level(q) == 2) __builtin_amdgcn_s_setprio(2);
+                        else if (level(q) == 1) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                }
                 double r[KB];
 #pragma unroll
                 for (int kk = 0; kk < KB; ++kk)
@@ -599,8 +627,8 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
                                               fc[3], fc[4], fc[5], fc[6], fc[7], fc[8]);
 #pragma unroll
                 for (int kk = 0; kk < KB; ++kk)
-                    cnt[j] += SAMPSON ? accumulate_inliers_sampson(r[kk], rcut, m.livemask[k0 + kk], es)
-                                      : accumulate_inliers(r[kk], rcut, m.livemask[k0 + kk], full_exec, es);
+                    if (SAMPSON) cnt[j] += accumulate_inliers_sampson(r[kk], rcut, m.livemask[k0 + kk], es);
+                    else accumulate_inliers<true>(r[kk], rcut, m.livemask[k0 + kk], full_exec, es, cnt[j]);
             }
             {   // this lane's partial sum p(w,l) of hypothesis j
                 const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -745,8 +773,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_score_lds(const double2* __restr
                     for (int kk = 0; kk < KB; ++kk)
 #pragma unroll
                         for (int h = 0; h < HG; ++h)
-                            cnt[h] += SAMPSON ? accumulate_inliers_sampson(r[kk][h], rcut, live[kk], p[h])
-                                              : accumulate_inliers(r[kk][h], rcut, live[kk], full_exec, p[h]);
+                            if (SAMPSON) cnt[h] += accumulate_inliers_sampson(r[kk][h], rcut, live[kk], p[h]);
+                            else accumulate_inliers<false>(r[kk][h], rcut, live[kk], full_exec, p[h], cnt[h]);
                 }
 #pragma unroll
                 for (int h = 0; h < HG; ++h) t[h] += p[h];

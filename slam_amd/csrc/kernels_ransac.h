@@ -738,16 +738,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_score_lds(const double2* __restr
             for (int h = 0; h < HG; ++h) { t[h] = 0.0; cnt[h] = 0; }
             // The four waves of a SIMD issue oldest first: left alone, the oldest wave would run through all of its
             // groups and leave the youngest to finish by itself, at the rate one wave can issue.  A wave with more
-            // groups still to do gets the higher priority, so the waves of a SIMD stay within one group of each other.
-            {
-                const int left = (ngroups - 1 - g) / (nslots * WAVES);  // groups after this one
-                if (left >= 3) __builtin_amdgcn_s_setprio(3);
-                else if (left == 2) __builtin_amdgcn_s_setprio(2);
-                else if (left == 1) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
+            // work still to do gets the higher priority.  What counts is how far apart the waves are at the END, and a
+            // wave with priority gains on the others slowly, so the levels get shorter towards the end: the last two
+            // slices of a wave's last group, the four before them, the ten before those, everything earlier.
+            const int left = (ngroups - 1 - g) / (nslots * WAVES);  // groups after this one
 #pragma unroll 1
             for (int w = 0; w < SLAM_SLICES; ++w) {
+                {
+                    const int rem = left * SLAM_SLICES + (SLAM_SLICES - 1 - w);  // slices after this one (wave-uniform)
+                    if (rem >= 16) __builtin_amdgcn_s_setprio(3);
+                    else if (rem >= 6) __builtin_amdgcn_s_setprio(2);
+                    else if (rem >= 2) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
                 double p[HG];
 #pragma unroll
                 for (int h = 0; h < HG; ++h) p[h] = 0.0;

@@ -8,7 +8,8 @@ rank 7, where LAPACK's answer moves by as much) and its inlier sum, which may di
 explains: |d errsum| <= 2 sqrt(errsum count) C dF + count C^2 dF^2 with C = max |x1||x0| (plus 1e-12 relative).
 A winner that differs only because two hypotheses with equal counts have inlier sums equal within that tolerance is
 the tie the reference itself leaves open (its outcome there depends on the LAPACK build): it shows up on exact data
-(no pixel noise), where the sums are rounding noise of 1e-25; such cases are counted and bounded, not failed.
+(no pixel noise), where the sums are rounding noise of 1e-25, and where the same eight matches are drawn twice in
+another order (small N); the test asserts that every such case is one of these two, counts them and bounds the count.
 tests/fuzz_case.py prints one case in detail."""
 import numpy as np
 import pytest
@@ -40,7 +41,8 @@ def test_random_shapes_against_c_restatement(seed):
         n0, _ = pipeline.normalize_points(d["pts0"], ctx=ctx)
         n1, _ = pipeline.normalize_points(d["pts1"], ctx=ctx)
         g = epipolar.ransac_detailed(n0, n1, H, threshold=thr, per_hypothesis=True, ctx=ctx)
-        o = co.ransac(n0, n1, co.sample(N, g["H"]), thr=thr)
+        idx = co.sample(N, g["H"])
+        o = co.ransac(n0, n1, idx, thr=thr)
         assert np.array_equal(g["counts"], o["counts"]), where
         Fg, Fo = g["F_all"].reshape(-1, 9), o["F"].reshape(-1, 9)
         sign = np.sign(np.sum(Fg * Fo, axis=1, keepdims=True))
@@ -54,6 +56,9 @@ def test_random_shapes_against_c_restatement(seed):
         if gi != oi:
             assert o["counts"][gi] == o["counts"][oi], where
             assert abs(o["errsums"][gi] - o["errsums"][oi]) <= tol[oi] + tol[gi], where
+            # Only two things produce such ties: exact data (no pixel noise), where the tied sums are rounding noise of
+            # all-inlier samples, and the same eight matches drawn twice in another order (small N).
+            assert noise == 0.0 or set(idx[gi].tolist()) == set(idx[oi].tolist()), where
             ties += 1
         else:
             assert np.array_equal(g["best_mask"], o["best_mask"]), where

@@ -23,6 +23,36 @@ NS = [8, 9, 12, 40, 85, 86, 200, 511, 512, 513, 1000, 2047, 2048, 2049, 3000, 40
 HS = [1, 2, 7, 8, 9, 63, 64, 65, 100, 333, 1000]
 
 
+def _one_case(ctx, N, H, frac, noise, thr, data_seed, where):
+    """One differential run; returns True when the winner was decided by rounding (see the module docstring)."""
+    d = synth.make_pair(N, frac, seed=data_seed, noise_px=noise)
+    n0, _ = pipeline.normalize_points(d["pts0"], ctx=ctx)
+    n1, _ = pipeline.normalize_points(d["pts1"], ctx=ctx)
+    g = epipolar.ransac_detailed(n0, n1, H, threshold=thr, per_hypothesis=True, ctx=ctx)
+    idx = co.sample(N, g["H"])
+    o = co.ransac(n0, n1, idx, thr=thr)
+    assert np.array_equal(g["counts"], o["counts"]), where
+    Fg, Fo = g["F_all"].reshape(-1, 9), o["F"].reshape(-1, 9)
+    sign = np.sign(np.sum(Fg * Fo, axis=1, keepdims=True))
+    dF = np.linalg.norm(Fg * sign - Fo, axis=1) / np.linalg.norm(Fo, axis=1)
+    assert dF.max() <= 1e-6, where
+    C = float(np.max(np.sqrt(1 + np.sum(n0 * n0, axis=1)) * np.sqrt(1 + np.sum(n1 * n1, axis=1))))
+    cnt = o["counts"].astype(np.float64)
+    tol = 2 * np.sqrt(o["errsums"] * cnt) * C * dF + cnt * (C * dF) ** 2 + 1e-12 * o["errsums"] + 1e-300
+    assert np.all(np.abs(g["errsums"] - o["errsums"]) <= tol), where
+    gi, oi = g["best_index"], o["best_index"]
+    if gi != oi:
+        assert o["counts"][gi] == o["counts"][oi], where
+        assert abs(o["errsums"][gi] - o["errsums"][oi]) <= tol[oi] + tol[gi], where
+        # Only two things produce such ties: exact data (no pixel noise), where the tied sums are rounding noise of
+        # all-inlier samples, and the same eight matches drawn twice in another order (small N).
+        assert noise == 0.0 or set(idx[gi].tolist()) == set(idx[oi].tolist()), where
+        return True
+    assert np.array_equal(g["best_mask"], o["best_mask"]), where
+    assert g["best_count"] == o["best_count"], where
+    return False
+
+
 @pytest.mark.parametrize("seed", (1, 2, 3))
 def test_random_shapes_against_c_restatement(seed):
     logger.set_log_level("WARN")
@@ -37,35 +67,30 @@ def test_random_shapes_against_c_restatement(seed):
         noise = float(rng.choice([0.0, 0.2, 0.5, 2.0]))
         thr = float(rng.choice([0.005, 0.005, 1e-4, 0.05]))
         where = f"seed {seed} case {case}: N={N} H={H} outliers={frac} noise={noise} thr={thr}"
-        d = synth.make_pair(N, frac, seed=1000 * seed + case, noise_px=noise)
-        n0, _ = pipeline.normalize_points(d["pts0"], ctx=ctx)
-        n1, _ = pipeline.normalize_points(d["pts1"], ctx=ctx)
-        g = epipolar.ransac_detailed(n0, n1, H, threshold=thr, per_hypothesis=True, ctx=ctx)
-        idx = co.sample(N, g["H"])
-        o = co.ransac(n0, n1, idx, thr=thr)
-        assert np.array_equal(g["counts"], o["counts"]), where
-        Fg, Fo = g["F_all"].reshape(-1, 9), o["F"].reshape(-1, 9)
-        sign = np.sign(np.sum(Fg * Fo, axis=1, keepdims=True))
-        dF = np.linalg.norm(Fg * sign - Fo, axis=1) / np.linalg.norm(Fo, axis=1)
-        assert dF.max() <= 1e-6, where
-        C = float(np.max(np.sqrt(1 + np.sum(n0 * n0, axis=1)) * np.sqrt(1 + np.sum(n1 * n1, axis=1))))
-        cnt = o["counts"].astype(np.float64)
-        tol = 2 * np.sqrt(o["errsums"] * cnt) * C * dF + cnt * (C * dF) ** 2 + 1e-12 * o["errsums"] + 1e-300
-        assert np.all(np.abs(g["errsums"] - o["errsums"]) <= tol), where
-        gi, oi = g["best_index"], o["best_index"]
-        if gi != oi:
-            assert o["counts"][gi] == o["counts"][oi], where
-            assert abs(o["errsums"][gi] - o["errsums"][oi]) <= tol[oi] + tol[gi], where
-            # Only two things produce such ties: exact data (no pixel noise), where the tied sums are rounding noise of
-            # all-inlier samples, and the same eight matches drawn twice in another order (small N).
-            assert noise == 0.0 or set(idx[gi].tolist()) == set(idx[oi].tolist()), where
-            ties += 1
-        else:
-            assert np.array_equal(g["best_mask"], o["best_mask"]), where
-            assert g["best_count"] == o["best_count"], where
+        ties += _one_case(ctx, N, H, frac, noise, thr, 1000 * seed + case, where)
     # the observed number goes to the log (pytest -s / -rP shows it), so that a drift of this count is visible
     print(f"seed {seed}: {ties} of {cases} winners decided by rounding (equal counts, inlier sums equal within tolerance)")
     assert ties <= cases // 8, f"{ties} of {cases} winners decided by rounding"
+
+
+def test_random_shapes_with_many_hypotheses_against_c_restatement():
+    """The same differential run where the hypotheses take the split path (a lane per hypothesis for the solve, the
+    scoring kernel with its matches in LDS, two-stage selection beyond 32768): more than 4096 hypotheses, on match
+    counts around the chunk boundaries of that kernel (512, 2048 and 4096 matches; several chunks beyond)."""
+    logger.set_log_level("WARN")
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(77)
+    ties = 0
+    shapes = [(15, 4097), (100, 5000), (512, 4104), (513, 6000), (2048, 8192), (2049, 4100), (4096, 12000), (4097, 5001),
+              (9000, 4500), (20000, 4097), (700, 33000), (3000, 40000)]
+    for case, (N, H) in enumerate(shapes):
+        frac = float(rng.choice([0.1, 0.3, 0.5, 0.8]))
+        noise = float(rng.choice([0.2, 0.5, 2.0]))
+        thr = float(rng.choice([0.005, 1e-4, 0.05]))
+        where = f"case {case}: N={N} H={H} outliers={frac} noise={noise} thr={thr}"
+        # (the iteration count that yields H hypotheses: the reference runs min(iterations, C(N, 8)) of them)
+        ties += _one_case(ctx, N, H, frac, noise, thr, 5000 + case, where)
+    print(f"{ties} of {len(shapes)} winners decided by rounding")
 
 
 @pytest.mark.parametrize("seed", (11, 12))

@@ -73,6 +73,11 @@ def test_noalloc_entry_point_with_several_chunks_of_matches_and_many_hypotheses(
     rec = torch.full((_lib.REC_LEN,), -7.0, dtype=torch.float64, device=dev)
     mask = torch.full((N,), 9, dtype=torch.uint8, device=dev)
     want_rec, want_mask = torch.empty_like(rec), torch.empty_like(mask)
+    # (a first, small call: the runtime loads the library's code object at the first launch of a process, which takes
+    # device memory of its own)
+    ctx.check(lib.slam_ransac_f_dev_noalloc(ctx.handle, p0.data_ptr(), p1.data_ptr(), 64, None, _lib.SAMPLER_COUNTER, 7, 0, 8,
+                                            0.005, rec.data_ptr(), None))
+    ctx.check(lib.slam_synchronize(ctx.handle))
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info(dev)[0]
     ctx.check(lib.slam_ransac_f_dev_noalloc(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 7, 0, H,

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the two-view initialisation hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N=1: plain; N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N=1 runs in this process.  N>1 needs one process per GPU: when the command is started plainly (no RANK in the
+environment) it starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a child
+process, before anything here has touched the GPU, passes the child's output through and exits with its code; started
+by torch.distributed.run itself (RANK set) it is one rank of the job.
 
 Step = one full RANSAC pass (sample -> eight-point solve -> score -> select) over one synthetic frame pair that is
 already resident in HBM: N=4096 matches, 30 % outliers, 2048 hypotheses (the configuration the headline metric is quoted on).
@@ -39,10 +44,55 @@ PEAK_FP32_VALU = 157.3          # TFLOP/s, MI355X vector FP32: quoted alongside,
 PEAK_HBM = 8000.0               # GB/s
 # the kernels are compute-bound ("mfma" class of the two roofline classes) but issue vector FP64, not MFMA; on this
 # part the two peaks coincide
+BOUND_UNIT = "valu_fp64"        # the unit that actually bounds them; "bound" keeps the line's two-class vocabulary (hbm | mfma)
 BOUND_DETAIL = "FP64 vector ALU issue (no MFMA instructions); MI355X's dense FP64 MFMA peak is the same 78.6 TFLOP/s"
 TRI_FLOP_PER_SOLVE = 700.0      # executed per DLT solve: D build/scaling 80, warm start 550, Jacobi check 70
 TRI_SOLVES_PER_POINT = 2.0      # candidates with opposite translations give exactly opposite points: two solves serve four
 TRI_BYTES_PER_POINT = 88.0      # algorithmic: 2 x 32 B in (count pass + write pass) + 24 B out
+
+
+def load_traffic(build_hash, path=None):
+    """profiles/traffic.json (written by tools/collect_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of
+    tools/profile_round.sh) if it was measured with the library build `build_hash`, else no figures and the reason:
+    counter bytes of other kernels than the ones that run now are not quoted."""
+    path = path or os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except Exception as e:
+        return {}, f"profiles/traffic.json not readable ({type(e).__name__})"
+    if t.get("build_hash") != build_hash:
+        return {}, (f"profiles/traffic.json was measured with library build {t.get('build_hash')}, the loaded library is "
+                    f"build {build_hash}: run tools/profile_round.sh and tools/collect_profiles.py for this build")
+    return t, None
+
+
+def relaunch_command(argv, gpus, port):
+    """Command line that runs this file as `gpus` ranks on this node (one process per GPU, rendezvous on loopback)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_relaunch(gpus, argv, environ, call=None):
+    """`--gpus N` with N > 1 started as a plain process: run the N ranks as a child job and return its exit code
+    (None: this process is the job - one GPU, or a rank that torch.distributed.run started).  Called before torch is
+    imported, so this process never initialises the GPU; the child is a new process, not an exec."""
+    if gpus <= 1 or "RANK" in environ:
+        return None
+    import subprocess
+    env = dict(environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = relaunch_command(argv, gpus, free_port())
+    print("bench.py: starting", gpus, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return (call or subprocess.call)(cmd, env=env)   # the child inherits stdout: rank 0 writes the JSON line there
 
 
 def main():
@@ -56,6 +106,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true")
     args = ap.parse_args()
+    rc = maybe_relaunch(args.gpus, sys.argv[1:], os.environ)
+    if rc is not None:
+        sys.exit(rc)
 
     # Libraries (RCCL's start-up banner among them) write to stdout; the contract is ONE JSON line there.  Keep the
     # real stdout aside and point descriptor 1 at stderr until the line is ready.
@@ -160,9 +213,9 @@ def main():
     # steady state, the short one with a little more fill per burst.
     BURSTS = max(args.bursts, 1)
 
-    def timed_bursts(jobs_for_burst):
+    def timed_bursts(jobs_for_burst, bursts=None):
         times, failed = [], 0
-        for _ in range(BURSTS):
+        for _ in range(bursts or BURSTS):
             barrier()
             t0 = time.perf_counter()
             for job in jobs_for_burst:
@@ -184,6 +237,15 @@ def main():
     rec = d_rec.cpu().numpy()
     assert all(torch.equal(r, recs[0]) for r in recs), "lanes disagree"
     value = world * N_HYP * args.steps / dt
+    # Steady state: the same step in long bursts, where the fill and drain of the internal streams no longer weigh
+    # (a burst of K=20 steps is mostly those).  Reported beside the headline, which keeps its K.
+    SS_STEPS, SS_BURSTS = 2000, 15
+    ss = timed_bursts([jobs[i % LANES] for i in range(SS_STEPS)], SS_BURSTS) / SS_STEPS
+    ss_med = float(np.median(ss))
+    steady = {"workload": "the headline step in bursts of 2000 (same brackets around each burst)", "steps_per_burst": SS_STEPS,
+              "bursts": SS_BURSTS, "ms_per_step": ss_med * 1e3, "ms_per_step_min": float(ss.min()) * 1e3,
+              "ms_per_step_max": float(ss.max()) * 1e3, "hypotheses_per_sec": world * N_HYP / ss_med,
+              "residual_evals_per_sec": world * N_HYP * N_MATCHES / ss_med}
     # the same K steps strictly one after the other (one stream): the latency of a single call
     ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
     bs = timed_bursts([jobs[0]] * args.steps)
@@ -204,15 +266,13 @@ def main():
     ctx.check(lib.slam_profile_enable(ctx.handle, 0))
     score_us = kern["score"]
     achieved = FLOP_PER_EVAL * N_HYP * N_MATCHES / (score_us * 1e-6) / 1e12
-    tpath = os.path.join(REPO, "profiles", "traffic.json")   # memory-side bytes per launch from rocprofv3 PMC passes
-    try:
-        traffic_file = json.load(open(tpath))
-    except Exception:
-        traffic_file = {}
+    # memory-side bytes per launch from rocprofv3 counter passes (tools/profile_round.sh); quoted only when they were
+    # taken with the build that is loaded now
+    traffic_file, traffic_why = load_traffic(_lib.build_hash())
     traffic = traffic_file.get("k_ransac_bytes_per_launch")
-    roofline = {"kernel": "k_ransac (sample+solve+score)", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": achieved, "peak": PEAK_FP64_VALU,
+    roofline = {"kernel": "k_ransac (sample+solve+score)", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": achieved, "peak": PEAK_FP64_VALU,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VALU,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_why or traffic_file.get("source"),
                 "avg_launch_us": score_us, "flop_per_launch": FLOP_PER_EVAL * N_HYP * N_MATCHES,
                 # matches in, per hypothesis 64 sampler words in and F, count, error sum out
                 "algorithmic_bytes_per_launch": N_MATCHES * 32 + N_HYP * (256 + 72 + 12),
@@ -226,12 +286,14 @@ def main():
                       "n_matches": N_MATCHES, "hypotheses": N_HYP, "outlier_fraction": OUTLIERS,
                       "sharding": "independent frame pairs per GPU, no collective"},
            "residual_evals_per_sec": value * N_MATCHES,
-           "bursts": BURSTS, "ms_per_step_min": float(bt.min()) / args.steps * 1e3,
+           "bursts": BURSTS, "steps_timed_total": BURSTS * args.steps, "ms_per_step_mean": float(bt.mean()) / args.steps * 1e3,
+           "ms_per_step_min": float(bt.min()) / args.steps * 1e3,
            "ms_per_step_max": float(bt.max()) / args.steps * 1e3,
            "steps_in_flight": LANES, "ms_per_step_one_stream": dt_serial / args.steps * 1e3,
            "ms_per_step_one_stream_min": float(bs.min()) / args.steps * 1e3,
            "ms_per_step_one_stream_max": float(bs.max()) / args.steps * 1e3,
            "winner": {"index": int(rec[_lib.REC_INDEX]), "inliers": int(rec[_lib.REC_COUNT])},
+           "aux_steady_state": steady, "library_build": _lib.build_hash(),
            "roofline": roofline}
 
     # ---- aux: steady-state scoring rate (large H: solve and launch overheads amortised), and the host-buffer path
@@ -265,7 +327,7 @@ def main():
         tfl = FLOP_PER_EVAL * HL * N_MATCHES / (sc_us * 1e-6) / 1e12
         out["aux_large_h"] = {"workload": "same pair, 65536 hypotheses (counter-based sampler), split solve/score/select path",
                               "hypotheses_per_sec": HL / bdt, "residual_evals_per_sec": HL * N_MATCHES / bdt,
-                              "roofline": {"kernel": "k_score_lds", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
+                              "roofline": {"kernel": "k_score_lds", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
                                            "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": tfl / PEAK_FP32_VALU,
                                            "traffic": traffic_file.get("k_score_lds_bytes_per_launch"),
                                            "algorithmic_bytes_per_launch": N_MATCHES * 32 + HL * 72 + HL * 12,
@@ -310,6 +372,12 @@ def main():
         # The library's own communicator (RCCL, one rank per GPU; a single rank when there is one GPU), set up after
         # the headline measurement so that its streams do not take part in that.
         pipeline.comm_init(ctx, rank, world)
+        n_comm = C.c_int(0)
+        ctx.check(lib.slam_comm_count(ctx.handle, None, C.byref(n_comm)))
+        # (one line per rank on stderr: the tail of a multi-GPU run shows how many ranks RCCL itself saw)
+        print(f"bench.py rank {rank}: world={world} local_rank={local} device={torch.cuda.get_device_name(local)} "
+              f"rccl_comm_count={n_comm.value}", file=sys.stderr, flush=True)
+        assert n_comm.value == world, f"RCCL communicator spans {n_comm.value} ranks, expected {world}"
 
         def shard_step():
             # this rank's range, then the exchange inside the library: all-gather of the 96-byte records and the
@@ -323,14 +391,18 @@ def main():
         t0 = time.perf_counter()
         for _ in range(3):
             shard_step()
-        sdt = (stop_clock() - t0) / 3
+        sdt = (stop_clock() - t0) / 3      # three calls queued back to back, one synchronisation at the end
+        barrier()
+        t0 = time.perf_counter()
+        shard_step()
+        sdt_sync = stop_clock() - t0       # one call, synchronised: the latency of a call
         win = e_rec.cpu().numpy()
         who = next(g for g in range(world) if pipeline.shard_range(H3, g, world)[0] <= int(win[_lib.REC_INDEX])
                    < pipeline.shard_range(H3, g, world)[1])
         if use_dist:
-            t = torch.tensor([sdt], dtype=torch.float64, device=dev)
+            t = torch.tensor([sdt, sdt_sync], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sdt = float(t.item())
+            sdt, sdt_sync = float(t[0].item()), float(t[1].item())
             # every rank must hold the same winner
             chk = torch.from_numpy(win).to(dev)
             ref = chk.clone()
@@ -344,7 +416,8 @@ def main():
                                                      f"{world} GPU(s), counter-based sampler, winners exchanged by slam_exchange_winner_dev "
                                                      "(RCCL all-gather of 96-byte records + merge kernel, no host round trip)",
                                          "scaling": "strong", "hypotheses_per_sec": H3 / sdt,
-                                         "residual_evals_per_sec": H3 * N3 / sdt, "ms_per_call": sdt * 1e3,
+                                         "residual_evals_per_sec": H3 * N3 / sdt, "ms_per_call_pipelined": sdt * 1e3,
+                                         "ms_per_call_synchronised": sdt_sync * 1e3,
                                          "winner": {"index": int(win[_lib.REC_INDEX]), "inliers": int(win[_lib.REC_COUNT]),
                                                     "rank": int(who)}, "all_ranks_agree": agree}
         del e_p0, e_p1
@@ -397,7 +470,7 @@ def main():
                       "value": world * NT * tsteps / tdt, "unit": "points/s", "points_per_gpu": NT,
                       "candidate_triangulations_per_sec": 4 * world * NT * tsteps / tdt,
                       "cheirality_counts": d_counts.cpu().tolist(),
-                      "roofline": {"kernel": "k_triangulate4", "bound": "mfma", "bound_detail": BOUND_DETAIL, "achieved": tf,
+                      "roofline": {"kernel": "k_triangulate4", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": tf,
                                    "peak": PEAK_FP64_VALU, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU,
                                    "avg_launch_ms": tri_ms, "flop_per_dlt_solve": TRI_FLOP_PER_SOLVE,
                                    "dlt_solves_per_point": TRI_SOLVES_PER_POINT,

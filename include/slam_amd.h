@@ -59,6 +59,10 @@ enum {
 int slam_create(int device, slam_ctx** out);
 void slam_destroy(slam_ctx* ctx);
 const char* slam_last_error(const slam_ctx* ctx); /* ctx may be NULL: text of the last slam_create failure */
+/* Identifies the sources this library was built from: the first 16 hex digits of the SHA-256 of the library's source
+ * files (slam_amd/csrc/Makefile: HASH).  Measurement files name it, so that counters taken with one build are not
+ * quoted for another.  No counterpart in the reference. */
+const char* slam_build_hash(void);
 /* use the caller's HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it */
 int slam_set_stream(slam_ctx* ctx, void* hip_stream);
 /* Number of internal streams (1..4, default 1) that successive slam_ransac_f_dev calls rotate over.  With more than
@@ -76,7 +80,11 @@ int slam_set_concurrency(slam_ctx* ctx, int lanes);
 int slam_set_scoring(slam_ctx* ctx, int mode);
 /* Waits for everything the context has queued, on every internal stream.  Returns SLAM_ESAMPLER when a sampler of an
  * asynchronous (_dev / job) call queued since the last check ran out of pre-generated words: those calls cannot
- * report it when they return. */
+ * report it when they return.  The flag is one sticky bit per context, reported ONCE by whichever checking call comes
+ * first (this one, or any synchronous host entry point, which checks before it returns) and cleared by that report:
+ * it says "some call queued on this context since the previous check overflowed", not which one.  A caller that
+ * mixes asynchronous and synchronous calls and needs to attribute the error calls slam_synchronize before the
+ * synchronous call.  (The condition needs 96 consecutive rejected words: probability below 1e-19 per iteration.) */
 int slam_synchronize(slam_ctx* ctx);
 /* Page-locked host memory for callers that want the host entry points to transfer at the full PCIe rate (the library
  * copies arrays in pageable memory through a staging area; arrays in page-locked memory go directly when they are
@@ -121,6 +129,11 @@ int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int
  *  - with d_idx == NULL and SLAM_SAMPLER_CPYTHON the context's MT19937 word table must already cover
  *    [it0, it0 + H) for this seed (any earlier call with that seed and range made it); otherwise SLAM_EINVAL.
  *    Pre-drawn indices and the counter-based sampler need no table;
+ *  - under HIP stream capture (the context's stream set with slam_set_stream is capturing) the CPython-compatible
+ *    sampler without pre-drawn indices is refused with SLAM_EINVAL: its word table belongs to the context and any
+ *    later call with another seed or range rewrites or moves it, so a replayed graph would draw other samples or read
+ *    freed memory.  Capture with d_idx (draw the indices once with slam_sample_indices and keep them in a buffer of
+ *    your own) or with SLAM_SAMPLER_COUNTER;
  *  - always on the context's ordered stream (slam_set_concurrency does not apply);
  *  - more than 4096 hypotheses on more than 4096 matches are scored by the fused kernel in ranges of 4096 hypotheses
  *    (the per-chunk partial tables of the usual large-H path are a buffer that grows): same bits, but every workgroup
@@ -166,6 +179,9 @@ int slam_merge_records(const double* records, int n_records, double* out);
 #define SLAM_COMM_ID_BYTES 128
 int slam_comm_unique_id(slam_ctx* ctx, void* id128);
 int slam_comm_init_rank(slam_ctx* ctx, const void* id128, int n_ranks, int rank); /* collective; destroyed with the context */
+/* Number of ranks RCCL itself reports for a communicator (ncclCommCount): the context's own when rccl_comm is NULL.
+ * For launchers and benchmarks that want to state how many ranks the exchange calls below really span. */
+int slam_comm_count(slam_ctx* ctx, void* rccl_comm, int* n_ranks);
 /* Hypothesis-sharded RANSAC: every rank passes the record its own range produced (device memory, SLAM_REC_LEN
  * doubles, e.g. d_record of slam_ransac_f_dev); after the call every rank's d_record holds the global winner:
  * all-gather of the records, then the rule above (more inliers, smaller inlier-error sum, earlier iteration) applied

@@ -29,6 +29,7 @@ SIGNATURES = {
     "slam_create": (_int, [_int, C.POINTER(_vp)]),
     "slam_destroy": (None, [_vp]),
     "slam_last_error": (C.c_char_p, [_vp]),
+    "slam_build_hash": (C.c_char_p, []),
     "slam_set_stream": (_int, [_vp, _vp]),
     "slam_set_concurrency": (_int, [_vp, _int]),
     "slam_set_scoring": (_int, [_vp, _int]),
@@ -49,6 +50,7 @@ SIGNATURES = {
     "slam_merge_records": (_int, [_vp, _int, _vp]),
     "slam_comm_unique_id": (_int, [_vp, _vp]),
     "slam_comm_init_rank": (_int, [_vp, _vp, _int, _int]),
+    "slam_comm_count": (_int, [_vp, _vp, C.POINTER(_int)]),
     "slam_exchange_winner_dev": (_int, [_vp, _vp, _vp]),
     "slam_allreduce_counts4_dev": (_int, [_vp, _vp, _vp]),
     "slam_merge_records_dev": (_int, [_vp, _vp, _int, _vp]),
@@ -74,6 +76,28 @@ SIGNATURES = {
     "slam_profile_read": (_int, [_vp, _int, C.POINTER(_f64), C.POINTER(_i64)]),
     "slam_profile_reset": (_int, [_vp]),
 }
+
+
+SOURCE_FILES = ("slam_amd.hip", "ctx.h", "exchange.h", "linalg.h", "kernels_ransac.h", "kernels_tri.h", "kernels_track.h",
+                "kernels_match.h", "../../include/slam_amd.h")   # the Makefile's $(SRC) $(HDR), in its order
+
+
+def source_hash():
+    """What slam_build_hash() of a library built from this tree's sources returns (None without the sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for name in SOURCE_FILES:
+            with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
+def build_hash():
+    """slam_build_hash() of the library that is loaded."""
+    return load().slam_build_hash().decode()
 
 
 class SlamError(RuntimeError):

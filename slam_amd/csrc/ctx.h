@@ -31,6 +31,7 @@ struct slam_prof {
 struct slam_ctx {
     int device = 0;
     int num_cus = 256;                  // compute units of the device
+    int score_workgroups = 0;           // SLAM_AMD_SCORE_WORKGROUPS: workgroups of the large-H scoring kernel (0: one per CU)
     hipStream_t own_stream = nullptr;   // lane 0
     hipStream_t stream = nullptr;       // the context's ordered stream: own_stream, or the caller's (slam_set_stream)
     hipStream_t cur = nullptr;          // stream the launch helper uses right now (stream, or a lane)

@@ -64,8 +64,10 @@ inline RcclApi& rccl() {
 
 // Winner among R records of SLAM_REC_LEN doubles under the reference's rule extended across ranks (more inliers, then
 // the smaller inlier-error sum, then the earlier iteration: src/epipolar.py:78-81), written to out (which may be one of
-// the inputs' rank slots or a separate buffer).  One wave; R is the number of ranks, a handful.
-__global__ __launch_bounds__(64) void k_merge_records(const double* __restrict__ recs, int R, double* __restrict__ out) {
+// the inputs' rank slots or a separate buffer: neither pointer is restrict-qualified, and the winner's twelve values
+// are loaded before the barrier and stored after it).  One wave; R is the number of ranks, a handful.  A record with a
+// NaN error sum never wins a comparison and never loses one it is the incumbent of: rank order decides.
+__global__ __launch_bounds__(64) void k_merge_records(const double* recs, int R, double* out) {
     int best = 0;
     for (int r = 1; r < R; ++r) {
         const double* x = recs + (size_t)r * SLAM_REC_LEN;
@@ -76,7 +78,9 @@ __global__ __launch_bounds__(64) void k_merge_records(const double* __restrict__
         else wins = x[SLAM_REC_INDEX] < y[SLAM_REC_INDEX];
         if (wins) best = r;
     }
-    if (threadIdx.x < SLAM_REC_LEN) out[threadIdx.x] = recs[(size_t)best * SLAM_REC_LEN + threadIdx.x];
+    const double v = threadIdx.x < SLAM_REC_LEN ? recs[(size_t)best * SLAM_REC_LEN + threadIdx.x] : 0.0;
+    __syncthreads();  // every load of the wave has completed before the first store (out may overlap recs)
+    if (threadIdx.x < SLAM_REC_LEN) out[threadIdx.x] = v;
 }
 
 }  // namespace slamx

@@ -58,9 +58,9 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     if (!ctx) return SLAM_ENOMEM;
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* g = getenv("SLAM_AMD_SCORE_WORKGROUPS")) {  // tuning aid: workgroups of the large-H scoring kernel
+    if (const char* g = getenv("SLAM_AMD_SCORE_WORKGROUPS")) {  // tuning aid: workgroups of the large-H scoring kernel only
         const int v = atoi(g);
-        if (v > 0) ctx->num_cus = v;
+        if (v > 0) ctx->score_workgroups = v;
     }
     auto fail = [&](const char* what, hipError_t err) {
         snprintf(g_create_err, sizeof g_create_err, "%s: %s", what, hipGetErrorString(err));
@@ -152,6 +152,11 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
+
+#ifndef SLAM_BUILD_HASH
+#define SLAM_BUILD_HASH "unknown"
+#endif
+extern "C" const char* slam_build_hash(void) { return SLAM_BUILD_HASH; }
 
 extern "C" const char* slam_last_error(const slam_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
 
@@ -472,8 +477,9 @@ static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int
         const int Ht = std::min(tile, H - t0);
         const int ngroups = (Ht + SLAM_SCORE_HG - 1) / SLAM_SCORE_HG;
         const int want_slots = (ngroups + SLAM_SCORE_WAVES - 1) / SLAM_SCORE_WAVES;
-        const int nslots = std::max(1, std::min(ctx->num_cus / std::max(1, std::min(nchunks, ctx->num_cus)), want_slots));
-        const dim3 grid((unsigned)std::min<int64_t>((int64_t)nchunks * nslots, ctx->num_cus));
+        const int wgs = ctx->score_workgroups > 0 ? ctx->score_workgroups : ctx->num_cus;
+        const int nslots = std::max(1, std::min(wgs / std::max(1, std::min(nchunks, wgs)), want_slots));
+        const dim3 grid((unsigned)std::min<int64_t>((int64_t)nchunks * nslots, wgs));
         double* pe = errsums + t0;
         int32_t* pc = counts + t0;
         if (nchunks > 1) {
@@ -622,6 +628,16 @@ extern "C" int slam_ransac_f_dev_noalloc(slam_ctx* ctx, const double* d_p0, cons
     }
     SLAM_REQUIRE(ctx, ctx->noalloc_scratch != nullptr, "the context has no scratch pointer");
     if (!d_idx && sampler == SLAM_SAMPLER_CPYTHON) {
+        // Under stream capture the launches would bake the word table's address and first iteration into the graph,
+        // and any later call with another seed or range rewrites that table in place or frees and reallocates it: a
+        // replay would then draw other samples, or read freed memory.  Refused; pre-drawn indices and the
+        // counter-based sampler depend on nothing that a later call can change.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        SLAM_HIP(ctx, hipStreamIsCapturing(ctx->stream, &cap));
+        SLAM_REQUIRE(ctx, cap == hipStreamCaptureStatusNone,
+                     "slam_ransac_f_dev_noalloc under stream capture: the CPython-compatible sampler reads a word table "
+                     "that later calls may rewrite or move, so a captured launch cannot be replayed safely; pass "
+                     "pre-drawn indices (slam_sample_indices) or use the counter-based sampler");
         // the MT19937 word table is generated on the host and uploaded into a buffer that may have to grow: not here
         const bool covered = ctx->raw_n > 0 && ctx->raw_seed == seed && it0 >= ctx->raw_it0 &&
                              it0 + H <= ctx->raw_it0 + ctx->raw_n;
@@ -938,6 +954,16 @@ static int exchange_comm(slam_ctx* ctx, void* rccl_comm, slamx::ncclComm_t* comm
         *comm = (slamx::ncclComm_t)ctx->comm;
         *n_ranks = ctx->comm_ranks;
     }
+    return SLAM_OK;
+}
+
+extern "C" int slam_comm_count(slam_ctx* ctx, void* rccl_comm, int* n_ranks) {
+    if (!ctx) return SLAM_EINVAL;
+    SLAM_REQUIRE(ctx, n_ranks != nullptr, "NULL pointer");
+    SLAM_TRY(slam_need_rccl(ctx));
+    slamx::ncclComm_t comm = rccl_comm ? (slamx::ncclComm_t)rccl_comm : (slamx::ncclComm_t)ctx->comm;
+    SLAM_REQUIRE(ctx, comm != nullptr, "no communicator: call slam_comm_init_rank first or pass one");
+    SLAM_RCCL(ctx, slamx::rccl().CommCount(comm, n_ranks));
     return SLAM_OK;
 }
 

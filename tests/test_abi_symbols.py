@@ -73,3 +73,9 @@ def test_binding_constants_equal_the_header():
             assert values[c_name] == getattr(_lib, py_name), c_name
             checked += 1
     assert checked >= 10
+
+
+def test_library_was_built_from_this_tree():
+    """slam_build_hash() of the loaded library equals the hash of the sources in the tree: a stale .so fails here."""
+    assert _lib.source_hash() is not None
+    assert _lib.build_hash() == _lib.source_hash()

@@ -49,6 +49,52 @@ def test_bench_line_contract(path):
             assert 0.0 < a["frac"] < 1.0 and a["frac"] == pytest.approx(a["achieved"] / a["peak"], rel=1e-12)
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_multi_gpu_run_starts_its_own_ranks():
+    """`python bench.py --gpus N` started plainly runs torch.distributed.run with N ranks as a child process and
+    returns its exit code; a rank of such a job (RANK set) and a one-GPU run do not relaunch."""
+    bench = _bench_module()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert bench.maybe_relaunch(8, argv, {"PATH": "/usr/bin"}, call=fake_call) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[k + 1:] == argv                       # the ranks get the same arguments
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "RANK" not in seen["env"]
+    called = []
+    assert bench.maybe_relaunch(8, argv, {"RANK": "3", "WORLD_SIZE": "8"}, call=lambda *a, **k: called.append(1)) is None
+    assert bench.maybe_relaunch(1, ["--gpus", "1"], {}, call=lambda *a, **k: called.append(1)) is None
+    assert not called
+
+
+def test_traffic_is_quoted_for_the_build_it_was_measured_with_only(tmp_path):
+    bench = _bench_module()
+    f = tmp_path / "traffic.json"
+    f.write_text(json.dumps({"build_hash": "0123456789abcdef", "k_ransac_bytes_per_launch": 5, "source": "x"}))
+    t, why = bench.load_traffic("0123456789abcdef", str(f))
+    assert t["k_ransac_bytes_per_launch"] == 5 and why is None
+    t, why = bench.load_traffic("fedcba9876543210", str(f))
+    assert t == {} and "0123456789abcdef" in why and "fedcba9876543210" in why
+    t, why = bench.load_traffic("x", str(tmp_path / "missing.json"))
+    assert t == {} and "not readable" in why
+    # the tracked file carries the stamp
+    assert "build_hash" in json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+
+
 def test_traffic_file_matches_the_last_counter_set():
     t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
     tag = t["source"].split("profiles/")[1].split("_counters.json")[0]

@@ -47,6 +47,32 @@ def test_merge_kernel_equals_host_rule(comm_ctx):
         assert np.array_equal(out_h, want)
 
 
+def test_merge_in_place_into_a_rank_slot(comm_ctx):
+    """The output may be one of the input slots: slot 0 receives the winner when the winner is another slot."""
+    import torch
+    ctx = comm_ctx
+    dev = torch.device("cuda", ctx.device)
+    rng = np.random.default_rng(6)
+    for n in (2, 5, 8):
+        recs = _records(rng, n)
+        recs[0, _lib.REC_COUNT] = 1                     # slot 0 loses
+        best, want = pipeline.merge_records(recs)
+        assert best != 0
+        d = torch.from_numpy(recs).to(dev)
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.slam_merge_records_dev(ctx.handle, d.data_ptr(), n, d.data_ptr()))
+        ctx.check(ctx.lib.slam_synchronize(ctx.handle))
+        got = d.cpu().numpy()
+        assert np.array_equal(got[0], want) and np.array_equal(got[1:], recs[1:])
+
+
+def test_comm_count_reports_the_communicator_size(comm_ctx):
+    import ctypes as C
+    n = C.c_int(-1)
+    comm_ctx.check(comm_ctx.lib.slam_comm_count(comm_ctx.handle, None, C.byref(n)))
+    assert n.value == 1
+
+
 def test_exchange_with_one_rank_keeps_the_record(comm_ctx):
     """A RANSAC call followed by the exchange on the same stream, no synchronisation in between: with one rank the
     global winner is the local one, bit for bit; the counts all-reduce leaves the counts as they are."""

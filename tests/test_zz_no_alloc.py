@@ -66,6 +66,13 @@ def test_noalloc_entry_point_with_several_chunks_of_matches_and_many_hypotheses(
     memory does not change across it."""
     import torch
     ctx = _lib.Context(0)
+    try:
+        _several_chunks_and_many_hypotheses(torch, ctx)
+    finally:
+        ctx.close()
+
+
+def _several_chunks_and_many_hypotheses(torch, ctx):
     dev = torch.device("cuda", ctx.device)
     lib = ctx.lib
     N, H = 300000, 4200   # 74 chunks: the partial tables of the allocating call take 3.7 MB

@@ -41,6 +41,7 @@ json.dump(counters, open(os.path.join(dst, f"{tag}_counters.json"), "w"), indent
 
 kr, ks, kt = counters["k_ransac (N=4096, H=2048)"], counters["k_score_lds (N=4096, H=65536)"], counters["k_triangulate4 (16 M points)"]
 traffic = {
+    "build_hash": open(os.path.join(src, "build_hash.txt")).read().strip(),   # slam_build_hash() of the library the passes ran
     "source": f"profiles/{tag}_counters.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), "
               "mean per dispatch; read side doubled (gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16-B-per-lane stream)",
     "k_ransac_bytes_per_launch": kr["memory_side_bytes_per_launch"],

@@ -10,6 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from slam_amd import _lib; print(_lib.build_hash())" > $OUT/build_hash.txt || exit 1
 cd /tmp
 timeout -k 10 300 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 timeout -k 10 120 python3 $ROOT/bench.py --steps 20 --warmup 5 --no-aux --no-cpu-baseline > $OUT/bench_20steps.json 2>> $OUT/bench.err || exit 1

@@ -157,6 +157,90 @@ def gen_ransac():
               buf.getvalue().strip())
 
 
+def gen_config2():
+    """The headline configuration run by the reference itself, every one of its 2048 iterations: N=4096 matches, 30 %
+    wrong, seed 2 (the pair of ransac_n4096.npz, which holds the points; they are not stored twice).  About a minute
+    of reference time.  Stored: every hypothesis' inlier count and error sum, the winner, its mask, the F the full call
+    returns, its log line, and every 64th hypothesis' F."""
+    d, n0, T0, n1, T1 = normalized_pair(4096, 0.3, 2)
+    held = np.load(os.path.join(HERE, "ransac_n4096.npz"))
+    assert np.array_equal(held["p0"], n0) and np.array_equal(held["p1"], n1)
+    tr = ransac_trace(n0, n1, 2048)
+    buf = io.StringIO()
+    logger.set_log_level("INFO")
+    with contextlib.redirect_stdout(buf):
+        F_full = epipolar.calculate_fundamental_matrix_with_ransac(n0, n1, iterations=2048)
+    logger.set_log_level("WARN")
+    assert np.array_equal(F_full, tr["F"][tr["best_index"]])
+    np.savez_compressed(os.path.join(HERE, "ransac_config2.npz"), iterations=np.int32(2048), F_full=F_full,
+                        log_line=np.array(buf.getvalue()), counts=tr["counts"], errsums=tr["errsums"],
+                        best_index=tr["best_index"], best_count=tr["best_count"], best_errsum=tr["best_errsum"],
+                        best_mask=np.packbits(tr["best_mask"]), idx=tr["idx"].astype(np.int16), F_every_64th=tr["F"][::64])
+    print("config2: winner", int(tr["best_index"]), "count", int(tr["best_count"]), buf.getvalue().strip())
+
+
+def gen_config4():
+    """One pair of the batched-sequence configuration through the reference's own caller-side functions: seed 100,
+    N=2048 matches, 30 % wrong, KITTI-like intrinsics, 1000 iterations (custom_slam.py:96-102, then
+    src/epipolar.py:87-136)."""
+    d = synth.make_pair(2048, 0.3, 100)
+    K = d["K"]
+    buf = io.StringIO()
+    logger.set_log_level("DEBUG")
+    with contextlib.redirect_stdout(buf):
+        F = custom_slam.normalize_points_and_find_fundamental_matrix(d["pts0"], d["pts1"])
+        E = epipolar.fundamental_to_essential_matrix(F, K)
+        pose, X = epipolar.calculate_pose_from_essential_matrix(E, d["pts0"], d["pts1"], K)
+    logger.set_log_level("WARN")
+    Rs, ts, counts = pose_trace(E, d["pts0"], d["pts1"], K)
+    n0, T0 = custom_slam.normalize_points(d["pts0"])
+    n1, T1 = custom_slam.normalize_points(d["pts1"])
+    tr = ransac_trace(n0, n1, 1000)
+    assert np.array_equal(T1.T @ tr["F"][tr["best_index"]] @ T0, F)
+    np.savez_compressed(os.path.join(HERE, "config4_pair.npz"), pts0=d["pts0"], pts1=d["pts1"], K=K, F=F, E=E, pose=pose, X=X,
+                        good=X[:, 2] > 0, cand_counts=counts, log=np.array(buf.getvalue()), counts=tr["counts"],
+                        errsums=tr["errsums"], best_index=tr["best_index"], best_count=tr["best_count"],
+                        best_mask=np.packbits(tr["best_mask"]))
+    print("config4 pair: winner", int(tr["best_index"]), "count", int(tr["best_count"]), "cheirality", counts,
+          buf.getvalue().strip().replace("\n", " | "))
+
+
+def gen_pose_tie():
+    """Pose recovery where two of the four candidates tie on the in-front count, so that the strict `>` of
+    src/epipolar.py:129 (the FIRST maximum in the order (R0,t0),(R0,t1),(R1,t0),(R1,t1) wins) decides.  Found by
+    searching small scenes of mostly wrong matches; the candidate order is that of the reference's SVD."""
+    found = 0
+    out = {}
+    for seed in range(2000, 4000):
+        N = 8 + seed % 9
+        d = synth.make_pair(N, 0.8, seed)
+        K = d["K"]
+        try:
+            F = custom_slam.normalize_points_and_find_fundamental_matrix(d["pts0"], d["pts1"])
+        except Exception:
+            continue
+        E = epipolar.fundamental_to_essential_matrix(F, K)
+        Rs, ts, counts = pose_trace(E, d["pts0"], d["pts1"], K)
+        top = counts.max()
+        if np.count_nonzero(counts == top) < 2 or top < 2:
+            continue
+        buf = io.StringIO()
+        logger.set_log_level("DEBUG")
+        with contextlib.redirect_stdout(buf):
+            pose, X = epipolar.calculate_pose_from_essential_matrix(E, d["pts0"], d["pts1"], K)
+        logger.set_log_level("WARN")
+        k = found
+        out[f"pts0_{k}"], out[f"pts1_{k}"], out[f"K_{k}"], out[f"E_{k}"] = d["pts0"], d["pts1"], K, E
+        out[f"cand_R_{k}"], out[f"cand_t_{k}"], out[f"cand_counts_{k}"] = Rs, ts, counts
+        out[f"pose_{k}"], out[f"X_{k}"] = pose, X
+        print("pose tie", k, "seed", seed, "N", N, "counts", counts, buf.getvalue().strip())
+        found += 1
+        if found == 6:
+            break
+    out["cases"] = np.int32(found)
+    np.savez_compressed(os.path.join(HERE, "pose_tie.npz"), **out)
+
+
 def gen_triangulate():
     out = {}
     a = np.array([[-1, -.5], [.3, .9]])
@@ -430,4 +514,7 @@ if __name__ == "__main__":
     gen_matching()
     gen_config1()
     gen_driver()
+    gen_config2()
+    gen_config4()
+    gen_pose_tie()
     print("python", sys.version.split()[0], "numpy", np.__version__)

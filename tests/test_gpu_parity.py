@@ -173,6 +173,25 @@ def test_ransac_config2_against_c_restatement(ctx):
     assert worst < F_TOL
 
 
+def test_ransac_config2_against_the_reference_itself(ctx):
+    """The headline configuration against the reference's own run of all 2048 iterations (golden ransac_config2):
+    every inlier count, the winner and its mask exact, error sums to 1e-9, F to 1e-6."""
+    pts, g = load_golden("ransac_n4096"), load_golden("ransac_config2")
+    r = epipolar.ransac_detailed(pts["p0"], pts["p1"], 2048, per_hypothesis=True)
+    assert r["H"] == 2048
+    assert np.array_equal(r["counts"], g["counts"])
+    assert np.allclose(r["errsums"], g["errsums"], rtol=1e-9, atol=0)
+    assert r["best_index"] == int(g["best_index"]) and r["best_count"] == int(g["best_count"])
+    assert np.array_equal(r["best_mask"], np.unpackbits(g["best_mask"])[:4096].astype(bool))
+    assert abs(r["best_errsum"] - float(g["best_errsum"])) < 1e-9 * float(g["best_errsum"])
+    assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(g["F_full"])) < F_TOL
+    for k, F in enumerate(g["F_every_64th"]):
+        assert rel_err(fix_sign_scale(r["F_all"][64 * k]), fix_sign_scale(F)) < F_TOL, k
+    # the reference's own indices handed in give the same bits as the draw on the GPU
+    r2 = epipolar.ransac_detailed(pts["p0"], pts["p1"], idx=g["idx"].astype(np.int32), per_hypothesis=True)
+    assert np.array_equal(r2["counts"], r["counts"]) and np.array_equal(r2["errsums"], r["errsums"])
+
+
 def test_ransac_large_n_heavy_outliers_against_c_restatement(ctx):
     """N=65536, 70% outliers (shape of the hypothesis-sharded configuration), counter-based sampler."""
     d = synth.make_pair(65536, 0.7, seed=3)
@@ -307,6 +326,30 @@ def test_pose_from_essential_golden(ctx, name, capsys):
     assert np.array_equal(pose, r["pose"]) and np.array_equal(X, r["X"])
 
 
+def test_pose_ties_keep_a_tied_candidate(ctx):
+    """Two candidates tied on the in-front count (golden pose_tie): the reference keeps the first of them in the order
+    its SVD routine happens to produce; here the order follows this library's SVD, so the pick is checked to be one
+    of the reference's tied candidates, with that candidate's pose and points."""
+    from slam_amd import util
+    g = load_golden("pose_tie")
+    same_pick = 0
+    for k in range(int(g["cases"])):
+        ref = g[f"cand_counts_{k}"]
+        r = epipolar.pose_detailed(g[f"E_{k}"], g[f"pts0_{k}"], g[f"pts1_{k}"], g[f"K_{k}"])
+        assert sorted(r["counts"].tolist()) == sorted(ref.tolist())
+        assert r["counts"][r["winner"]] == ref.max()
+        # strict `>`: the winner is the FIRST maximum of this library's own order
+        assert r["winner"] == int(np.argmax(r["counts"]))
+        tied = np.flatnonzero(ref == ref.max())
+        poses = [util.rotation_translation_to_pose(g[f"cand_R_{k}"][j], g[f"cand_t_{k}"][j]) for j in tied]
+        d = [np.abs(r["pose"] - q).max() for q in poses]
+        assert min(d) < 1e-9, k
+        same_pick += int(np.abs(r["pose"] - g[f"pose_{k}"]).max() < 1e-9)
+        if np.abs(r["pose"] - g[f"pose_{k}"]).max() < 1e-9:
+            assert point_err(r["X"], g[f"X_{k}"]) < X_TOL
+    print("pose ties: same pick as the reference in", same_pick, "of", int(g["cases"]), "cases")
+
+
 def test_pose_bulk_against_c_restatement(ctx):
     d = synth.make_pair(300000, 0.2, seed=6)
     E = synth.essential_from_motion(d["R"], d["t"])
@@ -335,6 +378,31 @@ def test_whole_pair_matches_reference(ctx, name):
     pose, X = epipolar.calculate_pose_from_essential_matrix(E, g["pts0"], g["pts1"], g["K"])
     assert np.allclose(pose, r["pose"], atol=1e-9)
     assert point_err(X, r["X"]) < 1e-7
+
+
+def test_config4_pair_matches_the_reference_itself(ctx):
+    """One pair of the batched configuration (seed 100, N=2048, 1000 iterations) against the reference's own run
+    through its caller-side functions (golden config4_pair)."""
+    g = load_golden("config4_pair")
+    r = pipeline.initialise_pair(g["pts0"], g["pts1"], g["K"])
+    assert int(r["record"][_lib.REC_INDEX]) == int(g["best_index"]) and int(r["record"][_lib.REC_COUNT]) == int(g["best_count"])
+    assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(g["F"])) < F_TOL
+    assert rel_err(fix_sign_scale(r["E"]), fix_sign_scale(g["E"])) < F_TOL
+    assert sorted(r["counts"].tolist()) == sorted(g["cand_counts"].tolist())
+    assert r["counts"][r["winner"]] == g["cand_counts"].max()
+    assert np.allclose(r["pose"], g["pose"], atol=1e-7)
+    assert point_err(r["X"], g["X"]) < X_TOL
+    assert np.array_equal(r["mask"], g["good"])
+    # per-hypothesis counts of the normalised pair, through the RANSAC entry point
+    n0, _ = pipeline.normalize_points(g["pts0"])
+    n1, _ = pipeline.normalize_points(g["pts1"])
+    d = epipolar.ransac_detailed(n0, n1, 1000, per_hypothesis=True)
+    assert np.array_equal(d["counts"], g["counts"])
+    assert np.array_equal(d["best_mask"], np.unpackbits(g["best_mask"])[:2048].astype(bool))
+    # and as a member of a batch
+    b = pipeline.initialise_pairs([(g["pts0"], g["pts1"])] * 3, g["K"])
+    for x in b:
+        assert np.array_equal(x["X"], r["X"]) and np.array_equal(x["pose"], r["pose"])
 
 
 # ---------------------------------------------------------------------------------------------- device-resident API

@@ -111,3 +111,37 @@ def test_c_tracking_ransac_matches_golden(name):
     assert r["best_index"] == int(g["best_index"])
     for h in range(len(g["idx"])):
         assert rel_err(r["poses"][h], g["poses"][h]) < 1e-6, h
+
+
+# ---------------------------------------------------------------------------------------------- headline sizes
+def test_c_ransac_config2_every_iteration_of_the_reference():
+    """The headline configuration (N=4096, 2048 hypotheses) as the reference itself scored it, all iterations."""
+    pts, g = load_golden("ransac_n4096"), load_golden("ransac_config2")
+    idx = g["idx"].astype(np.int32)
+    assert np.array_equal(co.sample(4096, 2048), idx)
+    r = co.ransac(pts["p0"], pts["p1"], idx, threads=8)
+    assert np.array_equal(r["counts"], g["counts"])
+    assert np.allclose(r["errsums"], g["errsums"], rtol=1e-9, atol=0)
+    assert r["best_index"] == int(g["best_index"]) == 695 and int(g["best_count"]) == 3082
+    assert np.array_equal(r["best_mask"], np.unpackbits(g["best_mask"])[:4096].astype(bool))
+    assert rel_err(fix_sign_scale(r["best_F"]), fix_sign_scale(g["F_full"])) < 1e-9
+    for k, F in enumerate(g["F_every_64th"]):
+        assert rel_err(fix_sign_scale(r["F"][64 * k]), fix_sign_scale(F)) < 1e-8, k
+
+
+def test_c_pose_ties_keep_a_tied_candidate():
+    """Two candidates tied on the in-front count: the restatement's own SVD orders the candidates differently from
+    LAPACK's, so its pick is checked to be ONE of the reference's tied candidates (which one LAPACK's order puts first
+    is a property of that library's sign choices, not of the algorithm)."""
+    from slam_amd import util
+    g = load_golden("pose_tie")
+    for k in range(int(g["cases"])):
+        E, K, p0, p1 = g[f"E_{k}"], g[f"K_{k}"], g[f"pts0_{k}"], g[f"pts1_{k}"]
+        counts_ref = g[f"cand_counts_{k}"]
+        pose, X, counts, w = co.pose_from_E(E, K, p0, p1, threads=1)
+        assert sorted(counts.tolist()) == sorted(counts_ref.tolist())
+        assert counts[w] == counts_ref.max()
+        tied = np.flatnonzero(counts_ref == counts_ref.max())
+        assert len(tied) >= 2
+        poses = [util.rotation_translation_to_pose(g[f"cand_R_{k}"][j], g[f"cand_t_{k}"][j]) for j in tied]
+        assert min(np.abs(pose - q).max() for q in poses) < 1e-9

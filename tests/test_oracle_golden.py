@@ -214,3 +214,32 @@ def test_config1_chain_restatement_matches_reference():
     assert np.allclose(r["pose"], g["pose"], atol=1e-9)
     assert rel_err(r["X"], g["X"]) < 1e-7
     assert np.array_equal(r["mask"], g["good"])
+
+
+def test_config4_pair_restatement_matches_reference():
+    """One pair of the batched configuration (N=2048, 1000 iterations) through the reference's caller-side functions."""
+    g = load_golden("config4_pair")
+    r = so.initialise_pair(g["pts0"], g["pts1"], g["K"])
+    assert np.array_equal(r["ransac"]["counts"], g["counts"])
+    assert r["ransac"]["best_index"] == int(g["best_index"])
+    assert np.array_equal(r["ransac"]["best_mask"], np.unpackbits(g["best_mask"])[:2048].astype(bool))
+    assert rel_err(fix_sign_scale(r["F"]), fix_sign_scale(g["F"])) < 1e-9
+    assert rel_err(fix_sign_scale(r["E"]), fix_sign_scale(g["E"])) < 1e-9
+    assert np.array_equal(r["cheirality"], g["cand_counts"])
+    assert np.allclose(r["pose"], g["pose"], atol=1e-10)
+    assert np.array_equal(r["mask"], g["good"])
+
+
+def test_pose_ties_first_maximum_wins():
+    """With LAPACK's SVD (the reference's) the candidate order is the reference's, and the strict `>` of
+    src/epipolar.py:129 keeps the first of the tied candidates."""
+    g = load_golden("pose_tie")
+    assert int(g["cases"]) >= 4
+    for k in range(int(g["cases"])):
+        pose, X, counts = so.pose_from_essential(g[f"E_{k}"], g[f"pts0_{k}"], g[f"pts1_{k}"], g[f"K_{k}"])
+        ref = g[f"cand_counts_{k}"]
+        assert np.array_equal(counts, ref) and np.count_nonzero(ref == ref.max()) >= 2
+        assert np.allclose(pose, g[f"pose_{k}"], atol=1e-12)
+        first = int(np.argmax(ref))
+        from slam_amd import util
+        assert np.allclose(pose, util.rotation_translation_to_pose(g[f"cand_R_{k}"][first], g[f"cand_t_{k}"][first]), atol=1e-12)

@@ -13,8 +13,11 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("SLA
 import torch  # noqa: E402
 from slam_amd import pipeline, synth  # noqa: E402
 
+# usage: stamps.py [N [H [json-file tag]]]   (with a file name: the phase table is also appended to it as one JSON record)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+JSON_OUT = sys.argv[3] if len(sys.argv) > 3 else None
+TAG = sys.argv[4] if len(sys.argv) > 4 else "untagged"
 ctx = _lib.Context(0)
 lib = ctx.lib
 dev = torch.device("cuda", 0)
@@ -45,6 +48,20 @@ for i, nme in enumerate(names):
     q = np.quantile(d[:, i], [0.5, 0.9, 0.99])
     print(f"  {nme:8s} median {q[0]:9.0f}  90% {q[1]:9.0f}  99% {q[2]:9.0f}  max {d[:, i].max():9.0f}")
 tot = st[:, -1] - st[:, 0]
+if JSON_OUT:
+    import json
+    rec = {"tag": TAG, "library": os.path.basename(_lib.LIB_PATH), "build_hash": lib.slam_build_hash().decode(), "N": N, "H": H,
+           "workgroups": int(nb), "unit": "shader cycles, per workgroup (thread 0 stamps)",
+           "phases": {nme: {"median": float(np.median(d[:, i])), "p90": float(np.quantile(d[:, i], 0.9)), "max": float(d[:, i].max())}
+                      for i, nme in enumerate(["draw", "null vector", "projection", "barrier before scoring", "score", "wave sum", "barrier and fold"])},
+           "workgroup_total": {"median": float(np.median(tot)), "max": float(tot.max())},
+           "first_start_to_last_end": float(st[:, -1].max() - t0)}
+    try:
+        allrecs = json.load(open(JSON_OUT))
+    except Exception:
+        allrecs = []
+    allrecs.append(rec)
+    json.dump(allrecs, open(JSON_OUT, "w"), indent=1)
 print(f"  workgroup total median {np.median(tot):.0f}  max {tot.max():.0f}; first start to last end {st[:, -1].max() - t0:.0f} cycles")
 starts = np.sort(st[:, 0] - t0)
 ends = np.sort(st[:, -1] - t0)

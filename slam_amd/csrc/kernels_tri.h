@@ -46,30 +46,43 @@ __device__ __forceinline__ double rcp_like_division(double x) {
 // coordinates (src/triangulation.py:179), which leaves the two smallest singular values close together and the
 // homogeneous coordinate small - pass SLAM_TRI_ANGLE_TOL_TIGHT.
 #define SLAM_TRI_ANGLE_TOL_TIGHT 1e-15
-template <int MAX_STEPS = SLAM_LEAST4_STEPS>
+// P0_IS_K_I0: the first camera is K [I|0] (pose recovery): its last column is zero, so rows 0 and 1 of D end in zero.
+//   The zeros are not computed, not scaled and not multiplied through; the Newton iteration of the warm start ends when
+//   the wave has converged (least_right_vector_4x4: Z03, ADAPTIVE_ROOT).
+template <int MAX_STEPS = SLAM_LEAST4_STEPS, bool P0_IS_K_I0 = false>
 __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, const double* __restrict__ P1, double u0,
                                                 double v0, double u1, double v1, double (&X)[3],
                                                 double angle_tol = SLAM_TRI_ANGLE_TOL) {
     double D[4][4], m[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        D[0][j] = fma(v0, P0[8 + j], -P0[4 + j]);
-        D[1][j] = fma(-u0, P0[8 + j], P0[j]);
+        if (P0_IS_K_I0 && j == 3) {
+            D[0][j] = 0.0;
+            D[1][j] = 0.0;
+        } else {
+            D[0][j] = fma(v0, P0[8 + j], -P0[4 + j]);
+            D[1][j] = fma(-u0, P0[8 + j], P0[j]);
+        }
         D[2][j] = fma(v1, P1[8 + j], -P1[4 + j]);
         D[3][j] = fma(-u1, P1[8 + j], P1[j]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = fmax(fmax(fabs(D[i][0]), fabs(D[i][1])), fmax(fabs(D[i][2]), fabs(D[i][3])));
+    for (int i = 0; i < 4; ++i) {
+        if (P0_IS_K_I0 && i < 2) m[i] = fmax(fmax(fabs(D[i][0]), fabs(D[i][1])), fabs(D[i][2]));
+        else m[i] = fmax(fmax(fabs(D[i][0]), fabs(D[i][1])), fmax(fabs(D[i][2]), fabs(D[i][3])));
+    }
     double im[4];  // reciprocals to within an ulp (the points are compared to 1e-5)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) im[j] = rcp_like_division(m[j]);
+    // (a camera K [I|0] or K [R|t] has no zero row, so no row maximum is zero: the plain reciprocal serves there)
+    for (int j = 0; j < 4; ++j) im[j] = P0_IS_K_I0 ? fast_rcp(m[j]) : rcp_like_division(m[j]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) D[i][j] *= im[j];
+        for (int j = 0; j < 4; ++j)
+            if (!(P0_IS_K_I0 && i < 2 && j == 3)) D[i][j] *= im[j];
     // polished until further rotations would turn y by less than 1e-12 rad (the points are compared to 1e-5)
     double yv[4];
-    least_right_vector_4x4<MAX_STEPS>(D, angle_tol, yv);
+    least_right_vector_4x4<MAX_STEPS, P0_IS_K_I0, P0_IS_K_I0>(D, angle_tol, yv);
     double Y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Y[i] = m[i] * yv[i];
@@ -134,8 +147,15 @@ __global__ __launch_bounds__(256) void k_triangulate(Cams cams, const double2* _
 __host__ __device__ inline int tri4_per_wg(int64_t matches_in_launch) {
     return matches_in_launch <= (1 << 16) ? 64 : (matches_in_launch <= (1 << 20) ? 256 : 1024);
 }
+// Beyond a million matches the waves' counts go to one of SLAM_TRI4_COUNT_SETS sets of four counters (the set is the
+// workgroup number modulo that), so that the atomics of different waves rarely meet on an address and a workgroup can
+// be short again; k_fold_counts4 adds the sets up.  (The launcher zeroes the sets.)
+#define SLAM_TRI4_COUNT_SETS 256
 #ifndef SLAM_TRI4_STEPS
 #define SLAM_TRI4_STEPS 0
+#endif
+#ifndef SLAM_TRI4_SPECIAL   // the first camera of pose recovery is K [I|0] (pose_prepare): use what that gives away
+#define SLAM_TRI4_SPECIAL true
 #endif
 #ifndef SLAM_TRI4_WAVES_PER_SIMD
 #define SLAM_TRI4_WAVES_PER_SIMD 4
@@ -143,7 +163,8 @@ __host__ __device__ inline int tri4_per_wg(int64_t matches_in_launch) {
 __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(const double* __restrict__ pw, const double2* __restrict__ p0,
                                                      const double2* __restrict__ p1, int64_t N, double* __restrict__ X4,
                                                      unsigned long long* __restrict__ counts4,
-                                                     const PairArgs* __restrict__ batch, int per_wg) {
+                                                     const PairArgs* __restrict__ batch, int per_wg,
+                                                     unsigned long long* __restrict__ count_sets) {
     if (batch) {
         const PairArgs& a = batch[blockIdx.y];
         pw = a.pw; p0 = a.r0; p1 = a.r1; N = a.N; X4 = a.X4; counts4 = a.counts4;
@@ -158,12 +179,16 @@ __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(c
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     int cnt[4] = {0, 0, 0, 0};  // wave-uniform
+    // (all addresses are a wave-uniform 64-bit base plus a 32-bit lane offset: per-lane 64-bit indices and pointers kept
+    // across the solve were what the register allocator spilled)
+    const int64_t wg0 = (int64_t)blockIdx.x * per_wg;
 #pragma unroll 1
     for (int k = 0; k < per_wg / 64; ++k) {
-        const int64_t i = (int64_t)blockIdx.x * per_wg + k * 64 + lane;
-        if ((int64_t)blockIdx.x * per_wg + k * 64 >= N) break;  // uniform
-        const bool live = i < N;
-        const double2 a = p0[live ? i : N - 1], b = p1[live ? i : N - 1];
+        const int64_t base = wg0 + k * 64;
+        if (base >= N) break;  // uniform
+        const int nlive = (int)(N - base < 64 ? N - base : 64);
+        const bool live = lane < nlive;
+        const int ll = live ? lane : nlive - 1;
         // Candidates 2 r and 2 r + 1 share the rotation and have opposite translations (pose_prepare): the last column
         // of the second camera changes sign and nothing else does, the first camera's last column is zero, so the whole
         // last column of D changes sign, the least singular vector changes the sign of its last component, and the
@@ -172,11 +197,14 @@ __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(c
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
             asm volatile("" ::: "memory");  // the LDS reads stay inside the loop: hoisted, they cost 40 registers
+            // (the match is read again for the second rotation - a cache hit - instead of occupying eight registers
+            // through the first solve)
+            const double2 a = (p0 + base)[ll], b = (p1 + base)[ll];
             const double* cand = s_pw + PW_CAND + 2 * r * PW_CAND_LEN;
             double X[3];
             // (sweeps only: with cameras K [R|t] the warm start is within the tolerance for all but one match in
             // thousands, and the Newton-like steps would cost the fourth wave per SIMD their registers)
-            triangulate_one<SLAM_TRI4_STEPS>(s_pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
+            triangulate_one<SLAM_TRI4_STEPS, SLAM_TRI4_SPECIAL>(s_pw + PW_P0, cand + PW_CAND_P1, a.x, a.y, b.x, b.y, X);
             const double tx = cand[PW_CAND_T], ty = cand[PW_CAND_T + 1], tz = cand[PW_CAND_T + 2];
             const double cx = cand[PW_CAND_CZ], cy = cand[PW_CAND_CZ + 1], cz = cand[PW_CAND_CZ + 2];
             const double s2 = (X[0] - tx) * cx + (X[1] - ty) * cy + (X[2] - tz) * cz;
@@ -185,16 +213,33 @@ __global__ __launch_bounds__(64, SLAM_TRI4_WAVES_PER_SIMD) void k_triangulate4(c
             cnt[0] += r == 0 ? n_pos : 0; cnt[1] += r == 0 ? n_neg : 0;
             cnt[2] += r == 1 ? n_pos : 0; cnt[3] += r == 1 ? n_neg : 0;
             if (live) {  // plane r holds candidate 2 r; candidate 2 r + 1 is its negative (candidate_point below)
-                double* o = X4 + ((size_t)r * (size_t)N + (size_t)i) * 3;
-                o[0] = X[0];
-                o[1] = X[1];
-                o[2] = X[2];
+                double* o = X4 + ((size_t)r * (size_t)N + (size_t)base) * 3;  // uniform
+                int l3;  // 3 * lane, formed here every time (volatile: kept across the solve it would be spilled)
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 1, %0" : "=v"(l3));
+                o[l3 + 0] = X[0];
+                o[l3 + 1] = X[1];
+                o[l3 + 2] = X[2];
             }
         }
     }
     if (lane < 4) {
         const int n = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
-        if (n) atomicAdd(&counts4[lane], (unsigned long long)n);
+        unsigned long long* dst = count_sets ? count_sets + 4 * (blockIdx.x % SLAM_TRI4_COUNT_SETS) : counts4;
+        if (n) atomicAdd(&dst[lane], (unsigned long long)n);
+    }
+}
+
+// counts4[c] += sum over the sets of count_sets[set][c]   (one workgroup of SLAM_TRI4_COUNT_SETS * 4 threads)
+__global__ __launch_bounds__(SLAM_TRI4_COUNT_SETS * 4) void k_fold_counts4(const unsigned long long* __restrict__ count_sets,
+                                                                         unsigned long long* __restrict__ counts4) {
+    __shared__ unsigned long long s_c[SLAM_TRI4_COUNT_SETS * 4];
+    const int t = threadIdx.x;
+    s_c[t] = count_sets[t];
+    __syncthreads();
+    if (t < 4) {
+        unsigned long long n = 0;
+        for (int k = 0; k < SLAM_TRI4_COUNT_SETS; ++k) n += s_c[4 * k + t];
+        counts4[t] += n;
     }
 }
 

@@ -107,7 +107,7 @@ extern "C" int slam_create(int device, slam_ctx** out) {
         return fail("hipGetSymbolAddress(scratch)", e);
     int rc = slam_reserve(ctx, ctx->flags, 16 * sizeof(int32_t));
     if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->record, 64 * sizeof(double));
-    if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->small, 1024 * sizeof(double));
+    if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->small, (1024 + 1024) * sizeof(double));  // small matrices, then the count sets of the bulk triangulation
     if (rc != SLAM_OK) {
         snprintf(g_create_err, sizeof g_create_err, "%s", ctx->err);
         slam_destroy(ctx);
@@ -1093,12 +1093,28 @@ extern "C" int slam_triangulate(slam_ctx* ctx, const double* P0, const double* P
 // ================================================================================================
 // pose recovery
 // ================================================================================================
+// sets of counters for launches beyond a million matches, or NULL (they live behind the small-matrix block)
+#define SLAM_SMALL_WORDS 1024
+#define SLAM_TRI4_PER_WG_SETS 256
+static unsigned long long* tri4_count_sets(slam_ctx* ctx, int64_t N) {
+    return N > ((int64_t)1 << 20) ? (unsigned long long*)((double*)ctx->small.p + SLAM_SMALL_WORDS) : nullptr;
+}
+
 static int tri4_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int64_t N, unsigned long long* d_counts4) {
     SLAM_TRY(slam_reserve(ctx, ctx->X4, (size_t)2 * (size_t)N * 3 * sizeof(double)));
-    const int per_wg = tri4_per_wg(N);
-    return slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + per_wg - 1) / per_wg)), dim3(64), 0,
-                       (const double*)ctx->small.p, (const double2*)d_p0, (const double2*)d_p1, N, (double*)ctx->X4.p,
-                       d_counts4, (const PairArgs*)nullptr, per_wg);
+    unsigned long long* sets = tri4_count_sets(ctx, N);
+    int per_wg = sets ? SLAM_TRI4_PER_WG_SETS : tri4_per_wg(N);
+    if (sets)
+        if (const char* g = getenv("SLAM_AMD_TRI4_PER_WG")) {  // tuning aid: matches per workgroup of the bulk launch
+            const int v = atoi(g);
+            if (v >= 64 && v % 64 == 0) per_wg = v;
+        }
+    if (sets) SLAM_HIP(ctx, hipMemsetAsync(sets, 0, SLAM_TRI4_COUNT_SETS * 4 * sizeof(unsigned long long), ctx->cur));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((N + per_wg - 1) / per_wg)), dim3(64), 0,
+                         (const double*)ctx->small.p, (const double2*)d_p0, (const double2*)d_p1, N, (double*)ctx->X4.p,
+                         d_counts4, (const PairArgs*)nullptr, per_wg, sets));
+    if (sets) SLAM_TRY(slam_launch(ctx, -1, k_fold_counts4, dim3(1), dim3(SLAM_TRI4_COUNT_SETS * 4), 0, (const unsigned long long*)sets, d_counts4));
+    return SLAM_OK;
 }
 
 extern "C" int slam_pose_candidates_dev(slam_ctx* ctx, const double* E_host, const double* K_host, const double* d_p0,
@@ -1359,7 +1375,7 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
     const int per_wg = tri4_per_wg(maxN);  // (each pair has counts of its own: the atomics of different pairs do not queue)
     SLAM_TRY(slam_launch(ctx, SLAM_K_TRIANGULATE, k_triangulate4, dim3((unsigned)((maxN + per_wg - 1) / per_wg), P), dim3(64), 0,
                          (const double*)nullptr, (const double2*)nullptr, (const double2*)nullptr, (int64_t)0,
-                         (double*)nullptr, (unsigned long long*)nullptr, all, per_wg));
+                         (double*)nullptr, (unsigned long long*)nullptr, all, per_wg, (unsigned long long*)nullptr));
     const unsigned eb = (unsigned)std::min<int64_t>(((int64_t)maxN * 3 + 255) / 256, 64);
     SLAM_TRY(slam_launch(ctx, -1, k_select_emit, dim3(eb, P), dim3(256), 0, (const double*)nullptr,
                          (const unsigned long long*)nullptr, (const double*)nullptr, (int64_t)0, (double*)nullptr,

@@ -153,16 +153,15 @@ def main():
             torch.cuda.synchronize()
 
     def stop_clock():
-        """Closing bracket: synchronise the device (every stream, the library's internal ones included), meet the
-        other ranks, read the clock.  The library's own end-of-queue check (slam_synchronize, which also fetches the
-        kernels' error flags) runs after the clock has been read: it is bookkeeping, not part of a step."""
+        """Closing bracket: the library's own synchronisation first (with several calls in flight it still holds the
+        last selections back, to be carried by a next call's kernel: slam_synchronize launches them and waits for
+        every internal stream), then the device, then the other ranks; then the clock is read."""
+        ctx.check(lib.slam_synchronize(ctx.handle))
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
-        t = time.perf_counter()
-        ctx.check(lib.slam_synchronize(ctx.handle))
-        return t
+        return time.perf_counter()
 
     # ---- inputs: one frame pair per rank, normalised as the reference's caller does, resident in HBM
     pair = synth.make_pair(N_MATCHES, OUTLIERS, seed=2 + rank)

@@ -28,6 +28,23 @@ struct slam_prof {
 
 #define SLAM_LANES 4  // internal streams that independent RANSAC calls rotate over
 
+// A selection that has not been launched yet: what k_select would be given.  With several calls in flight
+// (slam_set_concurrency) the fused kernel of the NEXT call on the same internal stream carries it (its first n_wgs
+// workgroups), or slam_synchronize and its like launch it on its own.
+struct slam_carried_select {
+    const int32_t* counts;
+    const double* errsums;
+    const double* Fall;
+    const double2 *p0, *p1;
+    double* record;
+    uint8_t* mask;
+    int64_t it0;
+    double rcut;
+    int H, N;
+    int n_wgs;   // workgroups of 512 threads that share the winner's mask (0: nothing pending)
+    int sampson;
+};
+
 struct slam_ctx {
     int device = 0;
     int num_cus = 256;                  // compute units of the device
@@ -50,13 +67,21 @@ struct slam_ctx {
     slam_buf counts;    // H int32        }
     slam_buf errsums;   // H f64          }
     slam_buf lane_F[SLAM_LANES], lane_counts[SLAM_LANES], lane_errsums[SLAM_LANES];  // lanes 1.. (index 0 unused)
+    // Calls whose selection is carried by the next call's kernel write their hypotheses into two scratch sets per
+    // internal stream in turn (one being read by the carried selection while the other is written), in one buffer:
+    // set s at carry_scratch[lane].p + s * carry_set_bytes[lane].
+    slam_buf carry_scratch[SLAM_LANES];
+    size_t carry_set_bytes[SLAM_LANES] = {};
+    unsigned carry_turn[SLAM_LANES] = {};
+    bool carry_selection = true;                   // SLAM_AMD_CARRY_SELECTION=0 turns the carrying off
+    slam_carried_select pending[SLAM_LANES] = {};  // n_wgs > 0: a selection waiting to be carried or launched
     slam_buf mask;      // N u8
     slam_buf record;    // SLAM_REC_LEN f64 + flags
     slam_buf raw;       // MT19937 words [raw_n][SLAM_RAW_WORDS]
     slam_buf X4;        // 2 candidate planes of N*3 f64 (candidates 0 and 2; 1 and 3 are their negatives)
     slam_buf X;         // N*3 f64 staging
     slam_buf small;     // small matrices: candidates, poses, T, E ...
-    slam_buf flags;     // int32[4] error flags written by kernels
+    slam_buf flags;     // int32[4] error flags written by kernels: .p is the device address of h_flags (mapped host memory), never freed as a buffer
     slam_buf track;     // tracking step: work block + per-hypothesis blocks
     slam_buf batch;     // slam_init_pairs: all pairs' points, planes and per-pair blocks
     hipEvent_t lane_event[SLAM_LANES + 1] = {};  // created on first use
@@ -108,8 +133,12 @@ struct slam_ctx {
         if (rc_ != SLAM_OK) return rc_; \
     } while (0)
 
+// launch the selections that wait to be carried (slam_carried_select), each on its internal stream
+int slam_flush_pending(slam_ctx* ctx);
+
 // wait for everything the context has queued, on its ordered stream and on every lane
 static inline int slam_sync_all(slam_ctx* ctx) {
+    SLAM_TRY(slam_flush_pending(ctx));
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int l = 0; l < SLAM_LANES; ++l)
         if (ctx->lane_stream[l] && ctx->lane_stream[l] != ctx->stream) SLAM_HIP(ctx, hipStreamSynchronize(ctx->lane_stream[l]));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ctx.h"          // slam_carried_select, SLAM_RAW_WORDS
 #include "kernels_tri.h"  // PairArgs
 #include "linalg.h"
 
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64) void k_sample(int kind, uint64_t seed, int64_t 
         for (int i = 0; i < 8; ++i)
             if (i < k) idx[(size_t)h * k + i] = out[i];
     }
-    if (!ok) atomicOr(&flags[0], 1);
+    if (!ok) raise_flag(flags);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(64) void k_solve(const double2* __restrict__ p0, co
     if (h >= H) return;
     int32_t sel[8];
     const bool ok = indices_for<SAMPLER>(h, N, idx_in, seed, it0, raw, raw_it0, s_words, s_pool, threadIdx.x, 64, sel);
-    if (!ok) atomicOr(&flags[0], 1);
+    if (!ok) raise_flag(flags);
     double F[9];
     solve_from_indices(p0, p1, N, sel, F);
 #pragma unroll
@@ -822,85 +823,6 @@ __global__ __launch_bounds__(256) void k_combine_chunks(const int32_t* __restric
     errsums[h] = e;
 }
 
-// K1+K2 fused for small H.  A workgroup of eight waves owns eight hypotheses:
-//   1. wave w draws the index set of hypothesis w (wave-parallel draw);
-//   2. wave 0 solves the eight hypotheses, eight lanes each (the arithmetic of k_solve's one-lane solve, spread over
-//      the lanes that own the columns, so F is bit-identical to the split path); the other waves request their
-//      matches of the first chunk meanwhile, wave 0 after its solve;
-//   3. the workgroup scores its hypotheses.
-// One launch, no round trip of F through memory between solve and score, and at most 128 registers, so that two
-// workgroups fit a CU and one of them can score while the other one solves.
-// workgroup barrier that waits for this wave's LDS traffic only: global loads stay in flight across it
-__device__ __forceinline__ void barrier_lds_only() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
-__global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32) / WAVES) void k_ransac(
-    // (what the first load of a wave needs comes first: the leading arguments are preloaded into scalar registers)
-    const uint32_t* __restrict__ raw, int64_t raw_it0, int64_t it0, int H, int N, const double2* __restrict__ p0,
-    const double2* __restrict__ p1, const int32_t* __restrict__ idx_in, uint64_t seed, double rcut,
-    double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags,
-    const PairArgs* __restrict__ batch) {
-    if (batch) {
-        const PairArgs& a = batch[blockIdx.y];
-        p0 = a.n0; p1 = a.n1; N = a.N; H = a.H; Fout = a.F_all; counts = a.counts; errsums = a.errsums;
-        if ((int)blockIdx.x * HB >= H) return;  // the grid is sized for the pair with most hypotheses
-    }
-    static_assert((HB == 8 || HB == 4) && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves the hypotheses, eight lanes each");
-    __shared__ double s_F[HB][9];
-    __shared__ double s_part[HB][WAVES][64];  // partial sums p(w,l) of the eight hypotheses
-    __shared__ int s_cnt[HB][WAVES];
-    __shared__ int32_t s_sel[HB][8];
-    __shared__ int32_t s_scratch[HB][16];
-    __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * HB : 1];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the branches on it below are scalar branches
-    const int h0 = blockIdx.x * HB;
-    SLAM_WALL_STAMP(0);
-    SLAM_STAMP(0);
-    SLAM_WG_LOG_BEGIN();
-    const int hs = min(h0 + min(wave, HB - 1), H - 1);  // surplus waves redo a hypothesis; their results are dropped
-    uint32_t word = 0;
-    if (SAMPLER == SLAM_SAMPLER_CPYTHON) word = raw[(size_t)(it0 + hs - raw_it0) * SLAM_RAW_WORDS + lane];
-    if (wave < HB) {
-        const bool ok = indices_for_wave<SAMPLER>(hs, N, word, idx_in, seed, it0, raw, raw_it0,
-                                                  s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * wave : 0),
-                                                  s_scratch[wave], s_sel[wave]);
-        if (!ok && lane == 0) atomicOr(&flags[0], 1);
-    }
-    barrier_lds_only();
-    SLAM_STAMP(1);
-    // Wave 0 solves the workgroup's eight hypotheses with all of its lanes, eight lanes per hypothesis, one column
-    // of the 9 x 8 system per lane (bit-identical to the one-lane solve of k_solve).  The matches of the first
-    // chunk are requested by the other waves now and by wave 0 after its solve: inside the solve they would only
-    // hold 64 registers, and with at most 128 two workgroups share a CU - one scores while the other one solves.
-    MatchChunk<PPL, WAVES> first;
-    if (wave == 0) {
-        const int g = (lane >> 3) & (HB - 1), c = lane & 7;  // (with four hypotheses the upper half of the wave repeats them)
-        const int i = min(max(s_sel[g][c], 0), N - 1);  // never read outside the arrays, whatever idx holds
-        double F[9];
-        solve8_by_eight_lanes(p0[i], p1[i], F);
-        if (c == 0 && lane < 8 * HB) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) s_F[g][q] = F[q];
-            if (h0 + g < H) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) Fout[(size_t)(h0 + g) * 9 + q] = F[q];
-            }
-        }
-        SLAM_STAMP(2);
-        first.load(p0, p1, N, 0);
-    } else {
-        first.load(p0, p1, N, 0);  // in flight while wave 0 solves
-    }
-    barrier_lds_only();
-    SLAM_STAMP(3);
-    score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_part, s_cnt);
-    SLAM_WALL_STAMP(1);
-    SLAM_WG_LOG_END((unsigned long long)(uintptr_t)Fout);
-}
-
 // ------------------------------------------------------------------------------------------------
 // K3: selection   (reference: src/epipolar.py:78-81 applied in iteration order)
 //   a later hypothesis replaces the incumbent iff it has more inliers, or as many and a strictly smaller errsum;
@@ -984,28 +906,25 @@ __global__ __launch_bounds__(1024) void k_select_partial(const int32_t* __restri
 #ifndef SLAM_SELECT_THREADS
 #define SLAM_SELECT_THREADS 1024
 #endif
-template <bool SAMPSON>
-__global__ __launch_bounds__(SLAM_SELECT_THREADS) void k_select(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
-                                                 const int32_t* __restrict__ index_of,  // NULL: entry h is hypothesis h
-                                                 const double* __restrict__ Fall, int H, int64_t it0,
-                                                 const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
-                                                 double rcut, double* __restrict__ record, uint8_t* __restrict__ mask,
-                                                 const PairArgs* __restrict__ batch) {
-    if (batch) {
-        const PairArgs& a = batch[blockIdx.y];
-        counts = a.counts; errsums = a.errsums; Fall = a.F_all; H = a.H; p0 = a.n0; p1 = a.n1; N = a.N; record = a.record;
-    }
-    constexpr int T = SLAM_SELECT_THREADS, W = T / 64;
-    static_assert(W == 4 || W == 16, "the fold below handles 4 or 16 wave winners");
-    __shared__ Best s_best[W];
+// Selection by one workgroup of T threads, number `wg` of `n_wgs` that share the matches of the winner's mask.
+// s_best: T / 64 entries of LDS.
+template <int T, bool SAMPSON>
+__device__ __forceinline__ void select_body(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
+                                            const int32_t* __restrict__ index_of,  // NULL: entry h is hypothesis h
+                                            const double* __restrict__ Fall, int H, int64_t it0,
+                                            const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
+                                            double rcut, double* __restrict__ record, uint8_t* __restrict__ mask, int wg,
+                                            int n_wgs, Best* s_best) {
+    constexpr int W = T / 64;
+    static_assert(W == 4 || W == 8 || W == 16, "the fold below handles 4, 8 or 16 wave winners");
     const int tid = threadIdx.x;
     SLAM_STAMP_SELECT(0);
     // The winner's mask needs every match: the grid's workgroups share the matches (workgroup x takes matches
     // x*T + tid, then strides by the grid), each finds the winner for itself - the reduction reads 12 bytes per
     // hypothesis, the mask 32 bytes per match through one CU's memory pipeline - and fetches its first match while
     // the reduction runs.  Workgroup 0 writes the record.
-    const int i_first = (int)blockIdx.x * T + tid;
-    const int stride = (int)gridDim.x * T;
+    const int i_first = wg * T + tid;
+    const int stride = n_wgs * T;
     const int i_pre = i_first < N ? i_first : N - 1;
     const double2 a_pre = p0[i_pre], b_pre = p1[i_pre];
     // scan: four entries per thread and pass, their loads issued together (clamped, so that they need no branch)
@@ -1036,7 +955,7 @@ __global__ __launch_bounds__(SLAM_SELECT_THREADS) void k_select(const int32_t* _
     const double* F = Fall + (size_t)w.index * 9;
     const double f00 = F[0], f01 = F[1], f02 = F[2], f10 = F[3], f11 = F[4], f12 = F[5], f20 = F[6], f21 = F[7],
                  f22 = F[8];
-    if (tid == 0 && blockIdx.x == 0) {
+    if (tid == 0 && wg == 0) {
         record[SLAM_REC_COUNT] = (double)w.count;
         record[SLAM_REC_ERRSUM] = w.errsum;
         record[SLAM_REC_INDEX] = (double)(it0 + w.index);
@@ -1059,6 +978,122 @@ __global__ __launch_bounds__(SLAM_SELECT_THREADS) void k_select(const int32_t* _
         for (int i = i_first + stride; i < N; i += stride) flag(i, p0[i], p1[i]);
     }
     SLAM_STAMP_SELECT(5);
+}
+
+template <bool SAMPSON>
+__global__ __launch_bounds__(SLAM_SELECT_THREADS) void k_select(const int32_t* __restrict__ counts, const double* __restrict__ errsums,
+                                                 const int32_t* __restrict__ index_of,  // NULL: entry h is hypothesis h
+                                                 const double* __restrict__ Fall, int H, int64_t it0,
+                                                 const double2* __restrict__ p0, const double2* __restrict__ p1, int N,
+                                                 double rcut, double* __restrict__ record, uint8_t* __restrict__ mask,
+                                                 const PairArgs* __restrict__ batch) {
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        counts = a.counts; errsums = a.errsums; Fall = a.F_all; H = a.H; p0 = a.n0; p1 = a.n1; N = a.N; record = a.record;
+    }
+    __shared__ Best s_best[SLAM_SELECT_THREADS / 64];
+    select_body<SLAM_SELECT_THREADS, SAMPSON>(counts, errsums, index_of, Fall, H, it0, p0, p1, N, rcut, record, mask,
+                                              (int)blockIdx.x, (int)gridDim.x, s_best);
+}
+
+// K1+K2 fused for small H.  A workgroup of eight waves owns eight hypotheses:
+//   1. wave w draws the index set of hypothesis w (wave-parallel draw);
+//   2. wave 0 solves the eight hypotheses, eight lanes each (the arithmetic of k_solve's one-lane solve, spread over
+//      the lanes that own the columns, so F is bit-identical to the split path); the other waves request their
+//      matches of the first chunk meanwhile, wave 0 after its solve;
+//   3. the workgroup scores its hypotheses.
+// One launch, no round trip of F through memory between solve and score, and at most 128 registers, so that two
+// workgroups fit a CU and one of them can score while the other one solves.
+// workgroup barrier that waits for this wave's LDS traffic only: global loads stay in flight across it
+__device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The selection of an EARLIER call, carried by a later call's fused kernel (the first n_wgs workgroups of the grid do
+// it, with the fused kernel's 512 threads each): with several calls in flight on the context's internal streams a call's
+// selection kernel is one launch more for the host to issue and one more link in its stream's chain of dependent
+// launches, and it keeps four to eight workgroups busy for as long as a whole scoring kernel.  n_wgs = 0: nothing carried.
+using CarriedSelect = slam_carried_select;  // ctx.h
+
+template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
+__global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32) / WAVES) void k_ransac(
+    // (what the first load of a wave needs comes first: the leading arguments are preloaded into scalar registers)
+    const uint32_t* __restrict__ raw, int64_t raw_it0, int64_t it0, int H, int N, const double2* __restrict__ p0,
+    const double2* __restrict__ p1, const int32_t* __restrict__ idx_in, uint64_t seed, double rcut,
+    double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags,
+    const PairArgs* __restrict__ batch, const CarriedSelect carried) {
+    const int n_carried = __builtin_amdgcn_readfirstlane(carried.n_wgs);
+    if ((int)blockIdx.x < n_carried) {  // (uniform per workgroup)
+        static_assert(WAVES == 8, "the carried selection runs with the fused kernel's 512 threads");
+        __shared__ Best s_best[WAVES];
+        if (carried.sampson)
+            select_body<64 * WAVES, true>(carried.counts, carried.errsums, nullptr, carried.Fall, carried.H, carried.it0,
+                                          carried.p0, carried.p1, carried.N, carried.rcut, carried.record, carried.mask,
+                                          (int)blockIdx.x, n_carried, s_best);
+        else
+            select_body<64 * WAVES, false>(carried.counts, carried.errsums, nullptr, carried.Fall, carried.H, carried.it0,
+                                           carried.p0, carried.p1, carried.N, carried.rcut, carried.record, carried.mask,
+                                           (int)blockIdx.x, n_carried, s_best);
+        return;
+    }
+    const int wg_index = (int)blockIdx.x - n_carried;
+    if (batch) {
+        const PairArgs& a = batch[blockIdx.y];
+        p0 = a.n0; p1 = a.n1; N = a.N; H = a.H; Fout = a.F_all; counts = a.counts; errsums = a.errsums;
+        if (wg_index * HB >= H) return;  // the grid is sized for the pair with most hypotheses
+    }
+    static_assert((HB == 8 || HB == 4) && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves the hypotheses, eight lanes each");
+    __shared__ double s_F[HB][9];
+    __shared__ double s_part[HB][WAVES][64];  // partial sums p(w,l) of the eight hypotheses
+    __shared__ int s_cnt[HB][WAVES];
+    __shared__ int32_t s_sel[HB][8];
+    __shared__ int32_t s_scratch[HB][16];
+    __shared__ uint8_t s_pool[SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * HB : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the branches on it below are scalar branches
+    const int h0 = wg_index * HB;
+    SLAM_WALL_STAMP(0);
+    SLAM_STAMP(0);
+    SLAM_WG_LOG_BEGIN();
+    const int hs = min(h0 + min(wave, HB - 1), H - 1);  // surplus waves redo a hypothesis; their results are dropped
+    uint32_t word = 0;
+    if (SAMPLER == SLAM_SAMPLER_CPYTHON) word = raw[(size_t)(it0 + hs - raw_it0) * SLAM_RAW_WORDS + lane];
+    if (wave < HB) {
+        const bool ok = indices_for_wave<SAMPLER>(hs, N, word, idx_in, seed, it0, raw, raw_it0,
+                                                  s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * wave : 0),
+                                                  s_scratch[wave], s_sel[wave]);
+        if (!ok && lane == 0) raise_flag(flags);
+    }
+    barrier_lds_only();
+    SLAM_STAMP(1);
+    // Wave 0 solves the workgroup's eight hypotheses with all of its lanes, eight lanes per hypothesis, one column
+    // of the 9 x 8 system per lane (bit-identical to the one-lane solve of k_solve).  The matches of the first
+    // chunk are requested by the other waves now and by wave 0 after its solve: inside the solve they would only
+    // hold 64 registers, and with at most 128 two workgroups share a CU - one scores while the other one solves.
+    MatchChunk<PPL, WAVES> first;
+    if (wave == 0) {
+        const int g = (lane >> 3) & (HB - 1), c = lane & 7;  // (with four hypotheses the upper half of the wave repeats them)
+        const int i = min(max(s_sel[g][c], 0), N - 1);  // never read outside the arrays, whatever idx holds
+        double F[9];
+        solve8_by_eight_lanes(p0[i], p1[i], F);
+        if (c == 0 && lane < 8 * HB) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s_F[g][q] = F[q];
+            if (h0 + g < H) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Fout[(size_t)(h0 + g) * 9 + q] = F[q];
+            }
+        }
+        SLAM_STAMP(2);
+        first.load(p0, p1, N, 0);
+    } else {
+        first.load(p0, p1, N, 0);  // in flight while wave 0 solves
+    }
+    barrier_lds_only();
+    SLAM_STAMP(3);
+    score_hypotheses<HB, PPL, WAVES, SAMPSON>(p0, p1, N, first, s_F, rcut, h0, H, counts, errsums, s_part, s_cnt);
+    SLAM_WALL_STAMP(1);
+    SLAM_WG_LOG_END((unsigned long long)(uintptr_t)Fout);
 }
 
 }  // namespace slamk

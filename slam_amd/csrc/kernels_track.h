@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64) void k_resect6(const double2* __restrict__ uv, 
         const bool ok = sample_cpython(raw + (size_t)(hh - raw_it0) * SLAM_RAW_WORDS, M, 6, out, s_words, s_pool, lane >> 4, 4);
 #pragma unroll
         for (int p = 0; p < 6; ++p) s_idx[lane >> 4][p] = min(max(out[p], 0), M - 1);  // never outside the arrays
-        if (!ok) atomicOr(&flags[0], 1);
+        if (!ok) raise_flag(flags);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -2,6 +2,7 @@
 // Everything is fully unrolled with compile-time indices so that the arrays live in VGPRs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include <type_traits>
 
@@ -15,6 +16,12 @@
 #define SLAM_RANK2_TOL 1e-15
 #endif
 namespace slamk {
+// The context's error flags live in page-locked host memory that the device writes directly (never, in practice: the
+// one flag says that a sampler ran out of pre-generated words), so that the host reads them after a synchronisation
+// without a copy.  System scope: the word is host memory.
+__device__ __forceinline__ void raise_flag(int32_t* flags) {
+    __hip_atomic_fetch_or(&flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 #ifdef SLAM_STAMPS
 __device__ unsigned long long g_dbg[8];  // sweep statistics of the rank-2 projection; counted only with SLAM_COUNT_SWEEPS
 #endif

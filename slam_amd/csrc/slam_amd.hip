@@ -91,6 +91,8 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     // test hook: SLAM_AMD_FAULT_INJECT=sampler makes the MT19937 table useless (all words rejected), so that the
     // SLAM_ESAMPLER path of every entry point can be exercised
     if (const char* inject = getenv("SLAM_AMD_FAULT_INJECT")) ctx->inject_sampler_fault = !strcmp(inject, "sampler");
+    // SLAM_AMD_CARRY_SELECTION=0: every call launches its own selection kernel also with several calls in flight
+    if (const char* c = getenv("SLAM_AMD_CARRY_SELECTION")) ctx->carry_selection = strcmp(c, "0") != 0;
     if ((e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio)) != hipSuccess)
         return fail("hipStreamCreate", e);
     ctx->stream = ctx->cur = ctx->own_stream;
@@ -100,21 +102,21 @@ extern "C" int slam_create(int device, slam_ctx** out) {
             return fail("hipStreamCreate", e);
     if ((e = hipHostMalloc((void**)&ctx->h_small, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess)
         return fail("hipHostMalloc", e);
-    if ((e = hipHostMalloc((void**)&ctx->h_flags, 16 * sizeof(int32_t), hipHostMallocDefault)) != hipSuccess)
+    // error flags: host memory the kernels write directly (linalg.h: raise_flag); flags.p is its device address
+    if ((e = hipHostMalloc((void**)&ctx->h_flags, 16 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return fail("hipHostMalloc", e);
+    memset(ctx->h_flags, 0, 16 * sizeof(int32_t));
+    if ((e = hipHostGetDevicePointer(&ctx->flags.p, ctx->h_flags, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
     // this device's copy of the code object's scratch array (the device is current here)
     if ((e = hipGetSymbolAddress((void**)&ctx->noalloc_scratch, HIP_SYMBOL(scratch))) != hipSuccess)
         return fail("hipGetSymbolAddress(scratch)", e);
-    int rc = slam_reserve(ctx, ctx->flags, 16 * sizeof(int32_t));
-    if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->record, 64 * sizeof(double));
+    int rc = slam_reserve(ctx, ctx->record, 64 * sizeof(double));
     if (rc == SLAM_OK) rc = slam_reserve(ctx, ctx->small, (1024 + 1024) * sizeof(double));  // small matrices, then the count sets of the bulk triangulation
     if (rc != SLAM_OK) {
         snprintf(g_create_err, sizeof g_create_err, "%s", ctx->err);
         slam_destroy(ctx);
         return rc;
     }
-    if ((e = hipMemsetAsync(ctx->flags.p, 0, 16 * sizeof(int32_t), ctx->stream)) != hipSuccess)
-        return fail("hipMemsetAsync", e);
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     *out = ctx;
     return SLAM_OK;
@@ -123,12 +125,14 @@ extern "C" int slam_create(int device, slam_ctx** out) {
 extern "C" void slam_destroy(slam_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    // selections that were never waited for are dropped, not launched: their output buffers are the caller's and may be gone
+    for (int l = 0; l < SLAM_LANES; ++l) ctx->pending[l].n_wgs = 0;
     if (ctx->stream) (void)slam_sync_all(ctx);  // a context that failed half-way through slam_create has no stream yet
     if (ctx->comm && slamx::rccl().ok) (void)slamx::rccl().CommDestroy((slamx::ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     if (ctx->xchg.p) (void)hipFree(ctx->xchg.p);
     slam_buf* bufs[] = {&ctx->pts, &ctx->norm, &ctx->idx, &ctx->F, &ctx->counts, &ctx->errsums, &ctx->mask, &ctx->record,
-                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->flags, &ctx->track, &ctx->match, &ctx->batch};
+                        &ctx->raw, &ctx->X4, &ctx->X, &ctx->small, &ctx->track, &ctx->match, &ctx->batch};
     for (slam_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int l = 0; l < SLAM_LANES; ++l) {
@@ -137,6 +141,7 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
         if (ctx->score_parts[l].p) (void)hipFree(ctx->score_parts[l].p);
         if (ctx->lane_counts[l].p) (void)hipFree(ctx->lane_counts[l].p);
         if (ctx->lane_errsums[l].p) (void)hipFree(ctx->lane_errsums[l].p);
+        if (ctx->carry_scratch[l].p) (void)hipFree(ctx->carry_scratch[l].p);
         if (l > 0 && ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
     }
     for (hipEvent_t ev : ctx->lane_event)
@@ -372,10 +377,9 @@ extern "C" int64_t slam_num_hypotheses(int64_t n_points, int64_t iterations) {
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int check_flags(slam_ctx* ctx) {
-    SLAM_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->flags.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_flags[0] & 1) {
-        SLAM_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (callers count on this: their downloads are complete afterwards)
+    if (__atomic_load_n(&ctx->h_flags[0], __ATOMIC_ACQUIRE) & 1) {
+        __atomic_store_n(&ctx->h_flags[0], 0, __ATOMIC_RELEASE);
         snprintf(ctx->err, sizeof ctx->err, "sampler ran out of random words for at least one iteration");
         return SLAM_ESAMPLER;
     }
@@ -426,24 +430,25 @@ static double square_cutoff(double thr) {
 // small H: one fused launch
 template <int SAMPLER, bool SAMPSON>
 static int launch_fused(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
-                        int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums) {
+                        int64_t it0, int H, double thr, double* F, int32_t* counts, double* errsums,
+                        const CarriedSelect& carried = CarriedSelect{}) {
     const uint32_t* raw = (const uint32_t*)ctx->raw.p;
     int32_t* flags = (int32_t*)ctx->flags.p;
     // Eight hypotheses per workgroup; four when eight would leave half of the CUs without a workgroup (the reference's
     // default of 1000 iterations: 250 workgroups instead of 125, 6.4 instead of 7.5 us at N=2048).  A hypothesis'
     // numbers do not depend on the choice.
     if ((H + SLAM_HB - 1) / SLAM_HB <= ctx->num_cus / 2) {
-        const dim3 grid((H + 3) / 4);
+        const dim3 grid((H + 3) / 4 + carried.n_wgs);
 #define SLAM_CALL(PPL, WAVES)                                                                                         \
     return slam_launch(ctx, SLAM_K_SCORE, k_ransac<4, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, raw, ctx->raw_it0, \
-                       it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr)
+                       it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr, carried)
         SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
     }
-    const dim3 grid((H + SLAM_HB - 1) / SLAM_HB);
+    const dim3 grid((H + SLAM_HB - 1) / SLAM_HB + carried.n_wgs);
 #define SLAM_CALL(PPL, WAVES)                                                                                         \
     return slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, WAVES, SAMPLER, SAMPSON>, grid, dim3(64 * WAVES), 0, raw, ctx->raw_it0, \
-                       it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr)
+                       it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr, carried)
     SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
 }
@@ -588,6 +593,84 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     return SLAM_OK;
 }
 
+// ---- selections carried by the next call's kernel (several calls in flight) ------------------------------------------
+// the selection of lane l that waits to be carried, launched on its own (on that lane's stream, behind the fused kernel
+// that produced its hypotheses)
+static int flush_lane(slam_ctx* ctx, int l) {
+    slam_carried_select& c = ctx->pending[l];
+    if (c.n_wgs == 0) return SLAM_OK;
+    hipStream_t keep = ctx->cur;
+    ctx->cur = ctx->lane_stream[l];
+    int rc;
+    if (c.sampson)
+        rc = slam_launch(ctx, SLAM_K_SELECT, k_select<true>, select_grid(c.N, c.mask), dim3(SLAM_SELECT_THREADS), 0, c.counts,
+                         c.errsums, (const int32_t*)nullptr, c.Fall, c.H, c.it0, c.p0, c.p1, c.N, c.rcut, c.record, c.mask,
+                         (const PairArgs*)nullptr);
+    else
+        rc = slam_launch(ctx, SLAM_K_SELECT, k_select<false>, select_grid(c.N, c.mask), dim3(SLAM_SELECT_THREADS), 0, c.counts,
+                         c.errsums, (const int32_t*)nullptr, c.Fall, c.H, c.it0, c.p0, c.p1, c.N, c.rcut, c.record, c.mask,
+                         (const PairArgs*)nullptr);
+    ctx->cur = keep;
+    c.n_wgs = 0;  // (also after a failed launch: it is not tried again)
+    return rc;
+}
+
+int slam_flush_pending(slam_ctx* ctx) {
+    int rc = SLAM_OK;
+    for (int l = 0; l < SLAM_LANES; ++l) {
+        const int r = flush_lane(ctx, l);
+        if (rc == SLAM_OK) rc = r;
+    }
+    return rc;
+}
+
+// A call in concurrency mode whose hypothesis scratch is the library's own: its fused kernel carries the selection of
+// the previous call on this lane, and its own selection waits for the next call (or for slam_synchronize).
+static int ransac_carry(slam_ctx* ctx, int lane, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
+                        int sampler, uint64_t seed, int64_t it0, int H, double thr, double* d_record, uint8_t* d_mask) {
+    SLAM_REQUIRE(ctx, d_p0 && d_p1 && d_record, "points or record pointer is NULL");
+    SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");
+    SLAM_REQUIRE(ctx, N <= SLAM_MAX_MATCHES, "more than 2^27 matches");
+    SLAM_REQUIRE(ctx, H >= 1 && H <= SLAM_FUSED_MAX_H && it0 >= 0, "H < 1 or it0 < 0");
+    SLAM_REQUIRE(ctx, d_idx || sampler == SLAM_SAMPLER_CPYTHON || sampler == SLAM_SAMPLER_COUNTER, "unknown sampler");
+    SLAM_REQUIRE(ctx, !d_idx || ((uintptr_t)d_idx & 15) == 0, "idx must be 16-byte aligned");
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t f_bytes = align256((size_t)H * 9 * sizeof(double)), e_bytes = align256((size_t)H * sizeof(double)),
+                 c_bytes = align256((size_t)H * sizeof(int32_t));
+    const size_t need = f_bytes + e_bytes + c_bytes;
+    if (need > ctx->carry_set_bytes[lane]) {
+        // the two sets move: the selection that still reads the old ones goes first (the stream orders the rest)
+        SLAM_TRY(flush_lane(ctx, lane));
+        SLAM_TRY(slam_reserve(ctx, ctx->carry_scratch[lane], 2 * need));
+        ctx->carry_set_bytes[lane] = need;
+    }
+    if (!d_idx && sampler == SLAM_SAMPLER_CPYTHON) SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));
+    char* set = (char*)ctx->carry_scratch[lane].p + (size_t)(ctx->carry_turn[lane]++ & 1u) * ctx->carry_set_bytes[lane];
+    double* F = (double*)set;
+    double* errsums = (double*)(set + f_bytes);
+    int32_t* counts = (int32_t*)(set + f_bytes + e_bytes);
+    const double2* p0 = (const double2*)d_p0;
+    const double2* p1 = (const double2*)d_p1;
+    const double cut = ctx->sampson ? thr : square_cutoff(thr);
+    const CarriedSelect carried = ctx->pending[lane];  // n_wgs == 0: nothing to carry
+    ctx->cur = ctx->lane_stream[lane];
+    int rc;
+#define SLAM_CARRY(SAMPLER_ID, IDX)                                                                                        \
+    rc = ctx->sampson ? launch_fused<SAMPLER_ID, true>(ctx, p0, p1, N, IDX, seed, it0, H, cut, F, counts, errsums, carried) \
+                      : launch_fused<SAMPLER_ID, false>(ctx, p0, p1, N, IDX, seed, it0, H, cut, F, counts, errsums, carried)
+    if (d_idx) { SLAM_CARRY(-1, d_idx); }
+    else if (sampler == SLAM_SAMPLER_CPYTHON) { SLAM_CARRY(SLAM_SAMPLER_CPYTHON, nullptr); }
+    else { SLAM_CARRY(SLAM_SAMPLER_COUNTER, nullptr); }
+#undef SLAM_CARRY
+    ctx->cur = ctx->stream;
+    if (rc != SLAM_OK) return rc;
+    slam_carried_select& next = ctx->pending[lane];
+    next.counts = counts; next.errsums = errsums; next.Fall = F; next.p0 = p0; next.p1 = p1; next.record = d_record;
+    next.mask = d_mask; next.it0 = it0; next.rcut = cut; next.H = H; next.N = N; next.sampson = ctx->sampson ? 1 : 0;
+    next.n_wgs = d_mask ? std::min((N + 511) / 512, 64) : 1;
+    return SLAM_OK;
+}
+
 extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                                  int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
                                  uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all) {
@@ -598,6 +681,10 @@ extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double
     // caller-supplied stream, or n = 1 (the default), every call stays on one stream, in order.
     int lane = 0;
     if (ctx->stream == ctx->own_stream && ctx->lanes_in_use > 1) lane = (int)(ctx->next_lane++ % (unsigned)ctx->lanes_in_use);
+    if (ctx->stream == ctx->own_stream && ctx->lanes_in_use > 1 && H <= SLAM_FUSED_MAX_H && !d_counts && !d_errsums &&
+        !d_F_all && !ctx->profiling && ctx->carry_selection)
+        return ransac_carry(ctx, lane, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask);
+    SLAM_TRY(flush_lane(ctx, lane));  // a selection that waits on this lane goes before this call's kernels
     if (lane > 0) {
         if (sampler == SLAM_SAMPLER_CPYTHON && !d_idx) SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));  // on the ordered stream
         if (!d_F_all) { SLAM_TRY(slam_reserve(ctx, ctx->lane_F[lane], (size_t)H * 9 * sizeof(double))); d_F_all = (double*)ctx->lane_F[lane].p; }
@@ -897,6 +984,7 @@ extern "C" int slam_merge_records(const double* records, int n_records, double* 
 // The exchange runs on the context's ordered stream.  With slam_set_concurrency(n > 1) the RANSAC calls before it ran
 // on the internal streams: the ordered stream waits (on the device, not on the host) for what they have queued so far.
 static int join_lanes(slam_ctx* ctx) {
+    SLAM_TRY(slam_flush_pending(ctx));  // selections that wait to be carried are part of what the exchange waits for
     if (ctx->stream != ctx->own_stream || ctx->lanes_in_use <= 1) return SLAM_OK;
     for (int l = 1; l < ctx->lanes_in_use; ++l) {
         if (!ctx->lane_stream[l] || ctx->lane_stream[l] == ctx->stream) continue;
@@ -1361,7 +1449,7 @@ extern "C" int slam_init_pairs(slam_ctx* ctx, const double* pts0, const double* 
     SLAM_TRY(slam_launch(ctx, SLAM_K_SCORE, k_ransac<SLAM_HB, PPL, 8, SLAM_SAMPLER_CPYTHON, false>, grid, dim3(512), 0,     \
                          (const uint32_t*)ctx->raw.p, ctx->raw_it0, (int64_t)0, 0, 0, (const double2*)nullptr,            \
                          (const double2*)nullptr, (const int32_t*)nullptr, (uint64_t)SLAM_SEED_BASE, rcut,                \
-                         (double*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)ctx->flags.p, part))
+                         (double*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)ctx->flags.p, part, CarriedSelect{}))
         if (cls == 0) SLAM_BATCH_RANSAC(1);
         else if (cls == 1) SLAM_BATCH_RANSAC(4);
         else SLAM_BATCH_RANSAC(8);

@@ -448,6 +448,54 @@ def test_device_calls_in_flight_match_serial(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- full benchmark sizes
+def test_carried_selections_equal_separate_launches(ctx):
+    """With several calls in flight a call's selection is carried by the next call's fused kernel on the same internal
+    stream (or launched by slam_synchronize): a mixed sequence of calls - shapes, samplers, with and without a mask,
+    one of them too long for the fused kernel - returns bit for bit what the same calls return one at a time."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    pairs = {}
+    for N, seed in ((4096, 2), (700, 31), (2048, 32), (9000, 33)):
+        d = synth.make_pair(N, 0.3, seed=seed)
+        n0, _ = so.normalize_points(d["pts0"])
+        n1, _ = so.normalize_points(d["pts1"])
+        pairs[N] = (torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev))
+    idx = np.empty((500, 8), dtype=np.int32)
+    ctx.check(lib.slam_sample_indices(ctx.handle, _lib.SAMPLER_COUNTER, 77, 0, 500, 2048, 8, _lib.ptr(idx)))
+    d_idx = torch.from_numpy(idx).to(dev)
+    # (N, H, sampler, seed, it0, with mask, pre-drawn indices)
+    calls = [(4096, 2048, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE, 0, True, False), (700, 300, _lib.SAMPLER_COUNTER, 5, 100, False, False),
+             (2048, 1000, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE, 0, True, False), (2048, 500, _lib.SAMPLER_COUNTER, 77, 0, True, True),
+             (9000, 4096, _lib.SAMPLER_COUNTER, 6, 0, True, False), (4096, 6000, _lib.SAMPLER_COUNTER, 7, 0, True, False),
+             (4096, 8, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE, 40, False, False), (700, 4000, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE, 0, True, False),
+             (4096, 2048, _lib.SAMPLER_CPYTHON, _lib.SEED_BASE, 0, True, False)] * 2
+
+    def run(lanes):
+        ctx.check(lib.slam_set_concurrency(ctx.handle, lanes))
+        recs = [torch.full((_lib.REC_LEN,), -3.0, dtype=torch.float64, device=dev) for _ in calls]
+        masks = [torch.full((c[0],), 9, dtype=torch.uint8, device=dev) for c in calls]
+        torch.cuda.synchronize()
+        for (N, H, sampler, seed, it0, with_mask, pre), rec, mask in zip(calls, recs, masks):
+            p0, p1 = pairs[N]
+            ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, d_idx.data_ptr() if pre else None,
+                                            sampler, seed, it0, H, _lib.DEFAULT_THRESHOLD, rec.data_ptr(),
+                                            mask.data_ptr() if with_mask else None, None, None, None))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        return [r.cpu().numpy() for r in recs], [m.cpu().numpy() for m in masks]
+
+    try:
+        want_r, want_m = run(1)
+        for lanes in (2, 3, 4):
+            got_r, got_m = run(lanes)
+            for k, c in enumerate(calls):
+                assert np.array_equal(got_r[k], want_r[k]), (lanes, k, c)
+                assert np.array_equal(got_m[k], want_m[k]), (lanes, k, c)
+                assert want_r[k][_lib.REC_COUNT] >= 8 and (not c[5] or want_m[k].sum() == want_r[k][_lib.REC_COUNT])
+    finally:
+        ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
+
+
 def test_config3_full_size_properties(ctx):
     """N=65536 matches, 70% outliers, 2^20 hypotheses (configuration 3) at full size: the unsharded run equals the
     merge of eight contiguous ranges bit for bit, and a sample of hypotheses is checked against the C restatement."""

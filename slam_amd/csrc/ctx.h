@@ -26,7 +26,9 @@ struct slam_prof {
     int64_t launches[SLAM_K_COUNT] = {};
 };
 
+#ifndef SLAM_LANES
 #define SLAM_LANES 4  // internal streams that independent RANSAC calls rotate over
+#endif
 
 // A selection that has not been launched yet: what k_select would be given.  With several calls in flight
 // (slam_set_concurrency) the fused kernel of the NEXT call on the same internal stream carries it (its first n_wgs
@@ -73,6 +75,7 @@ struct slam_ctx {
     slam_buf carry_scratch[SLAM_LANES];
     size_t carry_set_bytes[SLAM_LANES] = {};
     unsigned carry_turn[SLAM_LANES] = {};
+    bool f32_counts = true;                        // SLAM_AMD_F32_COUNTS=0 keeps long calls on the float64 scoring kernel
     bool carry_selection = true;                   // SLAM_AMD_CARRY_SELECTION=0 turns the carrying off
     slam_carried_select pending[SLAM_LANES] = {};  // n_wgs > 0: a selection waiting to be carried or launched
     slam_buf mask;      // N u8

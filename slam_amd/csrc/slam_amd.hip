@@ -10,6 +10,7 @@
 #include "ctx.h"
 #include "exchange.h"
 #include "kernels_ransac.h"
+#include "kernels_count32.h"
 #include "kernels_tri.h"
 #include "kernels_track.h"
 #include "kernels_match.h"
@@ -91,6 +92,8 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     // test hook: SLAM_AMD_FAULT_INJECT=sampler makes the MT19937 table useless (all words rejected), so that the
     // SLAM_ESAMPLER path of every entry point can be exercised
     if (const char* inject = getenv("SLAM_AMD_FAULT_INJECT")) ctx->inject_sampler_fault = !strcmp(inject, "sampler");
+    // SLAM_AMD_F32_COUNTS=0: long calls count in float64 as well (kernels_count32.h is not used)
+    if (const char* c = getenv("SLAM_AMD_F32_COUNTS")) ctx->f32_counts = strcmp(c, "0") != 0;
     // SLAM_AMD_CARRY_SELECTION=0: every call launches its own selection kernel also with several calls in flight
     if (const char* c = getenv("SLAM_AMD_CARRY_SELECTION")) ctx->carry_selection = strcmp(c, "0") != 0;
     if ((e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio)) != hipSuccess)
@@ -174,7 +177,7 @@ extern "C" int slam_set_stream(slam_ctx* ctx, void* hip_stream) {
 
 extern "C" int slam_set_concurrency(slam_ctx* ctx, int lanes) {
     if (!ctx) return SLAM_EINVAL;
-    SLAM_REQUIRE(ctx, lanes >= 1 && lanes <= SLAM_LANES, "lanes must be 1..4");
+    SLAM_REQUIRE(ctx, lanes >= 1 && lanes <= SLAM_LANES, "lanes out of range (1..4)");
     SLAM_TRY(slam_sync_all(ctx));
     ctx->lanes_in_use = lanes;
     ctx->next_lane = 0;
@@ -505,6 +508,103 @@ static int launch_split(slam_ctx* ctx, const double2* p0, const double2* p1, int
 }
 
 #define SLAM_FUSED_MAX_H 4096
+static constexpr int SLAM_MAX_MATCHES = 1 << 27;
+
+// workgroups of the selection kernel: one per SLAM_SELECT_THREADS matches when it also writes the winner's mask (at most 64)
+static dim3 select_grid(int N, const void* mask) {
+    return dim3(mask ? (unsigned)std::min((N + SLAM_SELECT_THREADS - 1) / SLAM_SELECT_THREADS, 64) : 1u);
+}
+
+// Large H without per-hypothesis error sums: the counts in float32 with a float64 re-check band (kernels_count32.h),
+// then the float64 error sums of the hypotheses that tie on the largest count, then the selection among those.
+// Layout of the call's work area (ctx->score_parts[lane]): float32 table, state words, tie list and tie tables.
+struct F32Area {
+    float* F32;
+    CountState* state;
+    int32_t* n_out;
+    int32_t* tie_index;
+    int32_t* tie_counts;
+    double* tie_errsums;
+    double* partial;
+    int cap;
+};
+#define SLAM_F32_MIN_EVALS ((int64_t)1 << 27)  // below this many (hypothesis, match) pairs the extra launches cost more than they save
+
+static int f32_area(slam_ctx* ctx, int lane, int H, int nchunks, F32Area* a) {
+    // ties one rescoring launch handles (its per-chunk sums take cap * nchunks doubles: 16 MiB at most)
+    const int cap = (int)std::min<int64_t>(H, std::max<int64_t>(64, ((int64_t)1 << 21) / nchunks));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += align256(bytes); return at; };
+    const size_t o_f32 = take((size_t)H * SLAM_F32_ROW * sizeof(float)), o_state = take(sizeof(CountState)), o_n = take(sizeof(int32_t)),
+                 o_ti = take((size_t)H * 4), o_tc = take((size_t)H * 4), o_te = take((size_t)H * 8),
+                 o_part = take((size_t)cap * nchunks * 8);
+    SLAM_TRY(slam_reserve(ctx, ctx->score_parts[lane], off));
+    char* b = (char*)ctx->score_parts[lane].p;
+    a->F32 = (float*)(b + o_f32); a->state = (CountState*)(b + o_state); a->n_out = (int32_t*)(b + o_n);
+    a->tie_index = (int32_t*)(b + o_ti); a->tie_counts = (int32_t*)(b + o_tc); a->tie_errsums = (double*)(b + o_te);
+    a->partial = (double*)(b + o_part); a->cap = cap;
+    return SLAM_OK;
+}
+
+#ifndef SLAM_COUNT_HG
+#define SLAM_COUNT_HG 4   // hypotheses a wave counts at a time
+#endif
+template <int SAMPLER>
+static int launch_count_f32(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
+                            int64_t it0, int H, double rcut, double* F, int32_t* counts, double* d_record, uint8_t* d_mask) {
+    const int ppl = N <= 2048 ? 4 : 8;  // the same limits as SLAM_DISPATCH_SHAPE (N <= 512 does not come here)
+    const int chunk = 512 * ppl;
+    const int nchunks = (N + chunk - 1) / chunk;
+    int lane = 0;
+    for (int l = 1; l < SLAM_LANES; ++l)
+        if (ctx->cur == ctx->lane_stream[l]) lane = l;
+    F32Area a;
+    SLAM_TRY(f32_area(ctx, lane, H, nchunks, &a));
+    SLAM_HIP(ctx, hipMemsetAsync(a.state, 0, sizeof(CountState), ctx->cur));
+    if (nchunks > 1) SLAM_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)H * sizeof(int32_t), ctx->cur));
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SOLVE, k_solve_f32<SAMPLER>, dim3((H + 63) / 64), dim3(64), 0, p0, p1, N, d_idx, seed, it0,
+                         H, (const uint32_t*)ctx->raw.p, ctx->raw_it0, F, a.F32, (int32_t*)ctx->flags.p));
+    const int ngroups = (H + SLAM_COUNT_HG - 1) / SLAM_COUNT_HG;
+    const int want_slots = (ngroups + SLAM_SCORE_WAVES - 1) / SLAM_SCORE_WAVES;
+    const int wgs = ctx->score_workgroups > 0 ? ctx->score_workgroups : ctx->num_cus;
+    const int nslots = std::max(1, std::min(wgs / std::max(1, std::min(nchunks, wgs)), want_slots));
+    const dim3 grid((unsigned)std::min<int64_t>((int64_t)nchunks * nslots, wgs));
+    if (ppl == 4)
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SCORE, k_count_f32<SLAM_COUNT_HG, 4, SLAM_SCORE_WAVES>, grid, dim3(64 * SLAM_SCORE_WAVES), 0,
+                             p0, p1, N, (const float*)a.F32, (const double*)F, H, rcut, nchunks, nslots, counts, nchunks > 1 ? 1 : 0, a.state));
+    else
+        SLAM_TRY(slam_launch(ctx, SLAM_K_SCORE, k_count_f32<SLAM_COUNT_HG, 8, SLAM_SCORE_WAVES>, grid, dim3(64 * SLAM_SCORE_WAVES), 0,
+                             p0, p1, N, (const float*)a.F32, (const double*)F, H, rcut, nchunks, nslots, counts, nchunks > 1 ? 1 : 0, a.state));
+    if (getenv("SLAM_AMD_DEBUG_F32")) {  // statistics of the re-check band (diagnostic)
+        CountState hs;
+        SLAM_HIP(ctx, hipStreamSynchronize(ctx->cur));
+        SLAM_HIP(ctx, hipMemcpy(&hs, a.state, sizeof hs, hipMemcpyDeviceToHost));
+        const double blocks = (double)H / SLAM_COUNT_HG * (N / 128.0);
+        fprintf(stderr, "f32 counts: N=%d H=%d max_count=%u band blocks=%u of %.0f (%.3f %%)\n", N, H, hs.max_count, hs.band_evals,
+                blocks, 100.0 * hs.band_evals / blocks);
+    }
+    if (nchunks > 1)
+        SLAM_TRY(slam_launch(ctx, -1, k_max_count, dim3((H + 8191) / 8192), dim3(256), 0, (const int32_t*)counts, H, a.state));
+    SLAM_TRY(slam_launch(ctx, -1, k_collect_ties, dim3((H + 255) / 256), dim3(256), 0, (const int32_t*)counts, H, a.state,
+                         a.tie_index));
+    // Usually one hypothesis has the largest count and the first launch pair does all there is; every hypothesis may
+    // tie, though (degenerate data), so the launches cover all H list positions, a.cap at a time.
+    const dim3 rgrid((unsigned)nchunks, (unsigned)std::min(a.cap, 64));
+    for (int t_base = 0; t_base < H; t_base += a.cap) {
+        if (ppl == 4)
+            SLAM_TRY(slam_launch(ctx, -1, k_rescore_ties<4>, rgrid, dim3(512), 0, p0, p1, N, (const double*)F, rcut,
+                                 (const CountState*)a.state, (const int32_t*)a.tie_index, t_base, a.cap, a.partial));
+        else
+            SLAM_TRY(slam_launch(ctx, -1, k_rescore_ties<8>, rgrid, dim3(512), 0, p0, p1, N, (const double*)F, rcut,
+                                 (const CountState*)a.state, (const int32_t*)a.tie_index, t_base, a.cap, a.partial));
+        SLAM_TRY(slam_launch(ctx, -1, k_fold_ties, dim3((a.cap + 255) / 256), dim3(256), 0, (const CountState*)a.state, t_base, a.cap,
+                             nchunks, (const double*)a.partial, a.tie_counts, a.tie_errsums, a.n_out));
+    }
+    SLAM_TRY(slam_launch(ctx, SLAM_K_SELECT, k_select_ties, select_grid(N, d_mask), dim3(SLAM_SELECT_THREADS), 0,
+                         (const int32_t*)a.tie_counts, (const double*)a.tie_errsums, (const int32_t*)a.tie_index,
+                         (const int32_t*)a.n_out, (const double*)F, it0, p0, p1, N, rcut, d_record, d_mask));
+    return SLAM_OK;
+}
 
 template <int SAMPLER>
 static int launch_ransac(slam_ctx* ctx, const double2* p0, const double2* p1, int N, const int32_t* d_idx, uint64_t seed,
@@ -533,17 +633,11 @@ static int launch_ransac(slam_ctx* ctx, const double2* p0, const double2* p1, in
                  : launch_split<SAMPLER, false>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, F, counts, errsums);
 }
 
-static constexpr int SLAM_MAX_MATCHES = 1 << 27;
-
-// workgroups of the selection kernel: one per SLAM_SELECT_THREADS matches when it also writes the winner's mask (at most 64)
-static dim3 select_grid(int N, const void* mask) {
-    return dim3(mask ? (unsigned)std::min((N + SLAM_SELECT_THREADS - 1) / SLAM_SELECT_THREADS, 64) : 1u);
-}
 
 static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                           int sampler, uint64_t seed, int64_t it0, int H, double thr, double* d_record,
                           uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all,
-                          bool no_alloc = false) {
+                          bool no_alloc = false, int errsums_requested = -1 /* -1: exactly when d_errsums is given */) {
     SLAM_REQUIRE(ctx, d_p0 && d_p1 && d_record, "points or record pointer is NULL");
     SLAM_REQUIRE(ctx, N >= 8, "fewer than 8 matches");          // reference: src/epipolar.py:60
     SLAM_REQUIRE(ctx, N <= SLAM_MAX_MATCHES, "more than 2^27 matches");  // the kernels address matches by 32-bit byte offsets
@@ -551,12 +645,25 @@ static int ransac_enqueue(slam_ctx* ctx, const double* d_p0, const double* d_p1,
     SLAM_REQUIRE(ctx, d_idx || sampler == SLAM_SAMPLER_CPYTHON || sampler == SLAM_SAMPLER_COUNTER, "unknown sampler");
     SLAM_REQUIRE(ctx, !d_idx || ((uintptr_t)d_idx & 15) == 0, "idx must be 16-byte aligned");
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    // Nobody reads the per-hypothesis error sums, the call is long and scores the reference's residual: counts in
+    // float32 with a float64 re-check band, error sums for the hypotheses that tie on the largest count only.
+    const bool want_errsums = errsums_requested < 0 ? d_errsums != nullptr : errsums_requested != 0;
+    const bool f32_counts = ctx->f32_counts && !want_errsums && !no_alloc && !ctx->sampson && H > SLAM_FUSED_MAX_H && N > 512 &&
+                            (int64_t)H * N >= SLAM_F32_MIN_EVALS;
     if (!d_F_all) { SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)H * 9 * sizeof(double))); d_F_all = (double*)ctx->F.p; }
     if (!d_counts) { SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t))); d_counts = (int32_t*)ctx->counts.p; }
-    if (!d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double))); d_errsums = (double*)ctx->errsums.p; }
+    if (!d_errsums && !f32_counts) { SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double))); d_errsums = (double*)ctx->errsums.p; }
     const double2* p0 = (const double2*)d_p0;
     const double2* p1 = (const double2*)d_p1;
     if (!ctx->sampson) thr = square_cutoff(thr);  // algebraic mode: from here on the threshold is the cutoff on |r|
+    if (f32_counts) {
+        if (d_idx) return launch_count_f32<-1>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, d_F_all, d_counts, d_record, d_mask);
+        if (sampler == SLAM_SAMPLER_CPYTHON) {
+            SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));
+            return launch_count_f32<SLAM_SAMPLER_CPYTHON>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_record, d_mask);
+        }
+        return launch_count_f32<SLAM_SAMPLER_COUNTER>(ctx, p0, p1, N, nullptr, seed, it0, H, thr, d_F_all, d_counts, d_record, d_mask);
+    }
     if (d_idx) {
         SLAM_TRY(launch_ransac<-1>(ctx, p0, p1, N, d_idx, seed, it0, H, thr, d_F_all, d_counts, d_errsums, no_alloc));
     } else if (sampler == SLAM_SAMPLER_CPYTHON) {
@@ -689,11 +796,12 @@ extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double
         if (sampler == SLAM_SAMPLER_CPYTHON && !d_idx) SLAM_TRY(slam_fill_raw_table(ctx, seed, it0, H));  // on the ordered stream
         if (!d_F_all) { SLAM_TRY(slam_reserve(ctx, ctx->lane_F[lane], (size_t)H * 9 * sizeof(double))); d_F_all = (double*)ctx->lane_F[lane].p; }
         if (!d_counts) { SLAM_TRY(slam_reserve(ctx, ctx->lane_counts[lane], (size_t)H * sizeof(int32_t))); d_counts = (int32_t*)ctx->lane_counts[lane].p; }
-        if (!d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->lane_errsums[lane], (size_t)H * sizeof(double))); d_errsums = (double*)ctx->lane_errsums[lane].p; }
     }
+    double* const caller_errsums = d_errsums;
+    if (lane > 0 && !d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->lane_errsums[lane], (size_t)H * sizeof(double))); d_errsums = (double*)ctx->lane_errsums[lane].p; }
     ctx->cur = ctx->lane_stream[lane] && ctx->stream == ctx->own_stream ? ctx->lane_stream[lane] : ctx->stream;
     const int rc = ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
-                                  d_errsums, d_F_all);
+                                  d_errsums, d_F_all, false, caller_errsums != nullptr);
     ctx->cur = ctx->stream;
     return rc;
 }
@@ -862,7 +970,7 @@ extern "C" int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, 
     SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t)));
     SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
     SLAM_TRY(ransac_enqueue(ctx, d0, d1, N, d_idx, sampler, seed, it0, H, threshold, (double*)ctx->record.p, d_mask,
-                            (int32_t*)ctx->counts.p, (double*)ctx->errsums.p, (double*)ctx->F.p));
+                            (int32_t*)ctx->counts.p, (double*)ctx->errsums.p, (double*)ctx->F.p, false, errsums != nullptr));
     // record and mask come back through the pinned area (behind the staged points) and are handed over after the
     // synchronisation of check_flags(); the optional per-hypothesis arrays go directly
     char* h_out = stage_area(ctx, out_at + 256 + (size_t)N);

@@ -496,6 +496,64 @@ def test_carried_selections_equal_separate_launches(ctx):
         ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
 
 
+@pytest.mark.parametrize("N,H,outliers,scale", [(4096, 65536, 0.3, 1.0), (65536, 8192, 0.7, 1.0), (3000, 50000, 0.5, 1.0),
+                                                 (1500, 100000, 0.3, 1.0), (4096, 40000, 0.3, 37.0), (9001, 20000, 0.1, 1e-3)])
+def test_float32_counts_equal_float64_scoring(ctx, N, H, outliers, scale):
+    """Long calls that do not ask for per-hypothesis error sums count inliers in float32 with a float64 re-check band
+    and score only the hypotheses that tie on the best count in float64: every count, the record (bit for bit) and the
+    mask equal those of the float64 scoring kernel, which a call that asks for the error sums takes.  `scale` stretches
+    the coordinates (the width of the band follows their size; the threshold does not)."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    d = synth.make_pair(N, outliers, seed=N + H)
+    n0, _ = so.normalize_points(d["pts0"])
+    n1, _ = so.normalize_points(d["pts1"])
+    p0, p1 = torch.from_numpy(n0 * scale).to(dev), torch.from_numpy(n1 * scale).to(dev)
+    out = []
+    for want_errsums in (True, False):
+        rec = torch.full((_lib.REC_LEN,), -1.0, dtype=torch.float64, device=dev)
+        mask = torch.full((N,), 7, dtype=torch.uint8, device=dev)
+        counts = torch.full((H,), -1, dtype=torch.int32, device=dev)
+        errs = torch.zeros(H, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 17, 5, H,
+                                        _lib.DEFAULT_THRESHOLD, rec.data_ptr(), mask.data_ptr(), counts.data_ptr(),
+                                        errs.data_ptr() if want_errsums else None, None))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        out.append((rec.cpu().numpy(), mask.cpu().numpy(), counts.cpu().numpy()))
+    (r64, m64, c64), (r32, m32, c32) = out
+    assert np.array_equal(c64, c32)
+    assert np.array_equal(r64, r32) and np.array_equal(m64, m32)
+    assert r64[_lib.REC_COUNT] == c64.max() == m64.sum()
+
+
+def test_float32_counts_with_many_ties(ctx):
+    """Few matches that every hypothesis fits or misses alike: many hypotheses tie on the best count, and the float64
+    error sums of all of them decide.  (N = 600 matches of which 590 lie on one plane-induced motion, pure inliers.)"""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    N, H = 600, 300000
+    d = synth.make_pair(N, 0.0, seed=99)
+    n0, _ = so.normalize_points(d["pts0"])
+    n1, _ = so.normalize_points(d["pts1"])
+    p0, p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+    recs = []
+    for want_errsums in (True, False):
+        rec = torch.full((_lib.REC_LEN,), -1.0, dtype=torch.float64, device=dev)
+        errs = torch.zeros(H, dtype=torch.float64, device=dev)
+        counts = torch.zeros(H, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 3, 0, H, 0.05,
+                                        rec.data_ptr(), None, counts.data_ptr(), errs.data_ptr() if want_errsums else None, None))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        recs.append(rec.cpu().numpy())
+        c = counts.cpu().numpy()
+    assert np.array_equal(recs[0], recs[1])
+    assert np.count_nonzero(c == c.max()) >= 2      # the case really has ties at the top
+
+
 def test_config3_full_size_properties(ctx):
     """N=65536 matches, 70% outliers, 2^20 hypotheses (configuration 3) at full size: the unsharded run equals the
     merge of eight contiguous ranges bit for bit, and a sample of hypotheses is checked against the C restatement."""

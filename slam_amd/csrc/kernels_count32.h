@@ -83,6 +83,14 @@ __global__ __launch_bounds__(64) void k_solve_f32(const double2* __restrict__ p0
     write_f32_row(F, F32out + (size_t)h * SLAM_F32_ROW);
 }
 
+// max(|a0|,|a1|,1) * max(|b0|,|b1|,1) of one match as a float32 rounded upwards; +infinity when a coordinate is not
+// finite or the product does not fit (the band then covers everything and the chunk is counted in float64)
+__device__ __forceinline__ float coordinate_scale(const double2 a, const double2 b) {
+    const double m = fmax(fmax(fabs(a.x), fabs(a.y)), 1.0) * fmax(fmax(fabs(b.x), fabs(b.y)), 1.0);
+    const bool finite = (fabs(a.x) + fabs(a.y) + fabs(b.x) + fabs(b.y)) < 1e150;  // (false for NaN)
+    return finite ? (float)(m * (1.0 + 1e-6)) : __builtin_inff();
+}
+
 // Device words shared by the kernels of one call (zeroed by the launcher before the count kernel)
 struct CountState {
     unsigned int max_count;   // largest inlier count over the hypotheses
@@ -138,14 +146,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
             if (i0 < N) {
                 const double2 a = p0[i0], b = p1[i0];
                 A.x = (float)a.x; A.z = (float)a.y; B.x = (float)b.x; B.z = (float)b.y;
-                const double m = fmax(fmax(fabs(a.x), fabs(a.y)), 1.0) * fmax(fmax(fabs(b.x), fabs(b.y)), 1.0);
-                mmax = fmaxf(mmax, (float)(m * (1.0 + 1e-6)));
+                mmax = fmaxf(mmax, coordinate_scale(a, b));
             }
             if (i1 < N) {
                 const double2 a = p0[i1], b = p1[i1];
                 A.y = (float)a.x; A.w = (float)a.y; B.y = (float)b.x; B.w = (float)b.y;
-                const double m = fmax(fmax(fabs(a.x), fabs(a.y)), 1.0) * fmax(fmax(fabs(b.x), fabs(b.y)), 1.0);
-                mmax = fmaxf(mmax, (float)(m * (1.0 + 1e-6)));
+                mmax = fmaxf(mmax, coordinate_scale(a, b));
             }
             s_m[w][q][0][l] = A;
             s_m[w][q][1][l] = B;
@@ -157,21 +163,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
         SLAM_STAMP_WAVE(1, clock64());
         for (int g = slot * WAVES + wave; g < ngroups; g += nslots * WAVES) {
             const int h0 = g * HG;
-            float lo[HG], hi[HG];
+            // Per hypothesis: w2 = half-width of the band in the SQUARED domain.  With d = fl32(r32^2 - rc2), rc2 = fl32(rcut^2)
+            // (one fma, one rounding; |rc2 - rcut^2| <= 3e-10):  d >= w2 excludes |r64| < rcut and d <= -w2 excludes
+            // |r64| >= rcut as soon as  w2 (1 - 2^-24) >= 2 rcut delta + delta^2 + 3e-10  (|r32| is within delta of |r64|),
+            // so a lane is certain when |d| >= w2, and then the SIGN of d is the answer.
+            float w2[HG];
             f32x2 fp[HG][5];  // F as pairs (f0,f1) (f2,f3) (f4,f5) (f6,f7) (f8,-)
-            int cnt[HG];
+            int cl[HG];       // per-lane inlier counts of this lane's matches (summed over the wave at the end)
 #pragma unroll
             for (int h = 0; h < HG; ++h) {
                 const float* Fh = F32 + (size_t)min(h0 + h, H - 1) * SLAM_F32_ROW + vzero;  // surplus slots rescore the last hypothesis
 #pragma unroll
                 for (int i = 0; i < 5; ++i) fp[h][i] = (f32x2){Fh[2 * i], Fh[2 * i + 1]};  // (entry 9 is not an F entry; unused as such)
                 const double delta = SLAM_F32_BAND * (double)Fh[9] * (double)Mf;
-                const double l = rcut - delta, u2 = rcut + delta;
-                lo[h] = (float)l * (1.0f - 1.2e-7f);   // rounded towards zero: never above rcut - delta
-                hi[h] = (float)u2 * (1.0f + 1.2e-7f);  // rounded upwards (NaN when the product overflowed: see below)
-                if (!(delta < rcut)) { lo[h] = 0.f; hi[h] = __builtin_inff(); }  // band covers everything (also for NaN)
-                cnt[h] = 0;
+                const double w = (2.0 * rcut * delta + delta * delta) * (1.0 + 1e-6) + 1e-9;
+                w2[h] = (float)w * (1.0f + 1.2e-7f);                      // rounded upwards
+                if (!(delta < rcut)) w2[h] = __builtin_inff();            // band covers everything (also for NaN)
+                cl[h] = 0;
             }
+            const f32x2 nrc2 = {-(float)(rcut * rcut), 0.f};
             const int left = (ngroups - 1 - g) / (nslots * WAVES);  // groups after this one
 #pragma unroll 1
             for (int w = 0; w < SLAM_SLICES; ++w) {
@@ -182,11 +192,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
                     else if (rem >= 2) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
+                unsigned int bits[HG];  // sign bits of d, one per turn of this slice (bit set: inside, if certain)
+                float mind[HG];         // smallest |d| of this lane's turns of the slice
+#pragma unroll
+                for (int h = 0; h < HG; ++h) { bits[h] = 0u; mind[h] = __builtin_inff(); }
 #pragma unroll
                 for (int q = 0; q < PAIRS; ++q) {
                     const float4 A = s_m[w][q][0][lane], B = s_m[w][q][1][lane];
                     const f32x2 a0 = {A.x, A.y}, a1 = {A.z, A.w}, b0 = {B.x, B.y}, b1 = {B.z, B.w};
-                    unsigned long long bx[HG], by[HG], any = 0ull;
 #pragma unroll
                     for (int h = 0; h < HG; ++h) {
                         // l0 = b0 f0 + (b1 f3 + f6), l1 = b0 f1 + (b1 f4 + f7), l2 = b0 f2 + (b1 f5 + f8): the chain of `residual`
@@ -194,38 +207,49 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
                         const f32x2 l1 = pk_fma_b<1>(b0, fp[h][0], pk_fma_bc<0, 1>(b1, fp[h][2], fp[h][3]));
                         const f32x2 l2 = pk_fma_b<0>(b0, fp[h][1], pk_fma_bc<1, 0>(b1, fp[h][2], fp[h][4]));
                         const f32x2 r = pk_fma(l0, a0, pk_fma(l1, a1, l2));
-                        const unsigned long long ix = __ballot(fabsf(r.x) < lo[h]), iy = __ballot(fabsf(r.y) < lo[h]);
-                        const unsigned long long ux = __ballot(fabsf(r.x) < hi[h]), uy = __ballot(fabsf(r.y) < hi[h]);
-                        cnt[h] += __popcll(ix) + __popcll(iy);
-                        bx[h] = ux & ~ix;
-                        by[h] = uy & ~iy;
-                        any |= bx[h] | by[h];
-                    }
-#ifdef SLAM_C32_NOSLOW
-                    if (any == 0x123456789ull) {
-#else
-                    if (any != 0ull) {  // (wave-uniform, rare) the lanes inside a band: float64, as the float64 kernels do it
-#endif
-                        ++band_seen;
-                        // (unrolled: the arrays above must keep compile-time indices to stay in registers)
-#pragma unroll
-                        for (int h = 0; h < HG; ++h) {
-#pragma unroll
-                            for (int half = 0; half < 2; ++half) {
-                                const unsigned long long band = half ? by[h] : bx[h];
-                                if (band == 0ull) continue;
-                                const bool mine = ((band >> lane) & 1ull) != 0ull;
-                                const int i = base + (2 * q + half) * 64 * SLAM_SLICES + w * 64 + lane;
-                                const int ii = mine ? i : 0;  // a lane in the band holds a real match (NaN lanes never are)
-                                const double2 a = p0[ii], b = p1[ii];
-                                const double* Fd = Fall + (size_t)min(h0 + h, H - 1) * 9;
-                                const double r = residual<false>(a.x, a.y, b.x, b.y, Fd[0], Fd[1], Fd[2], Fd[3], Fd[4], Fd[5],
-                                                                 Fd[6], Fd[7], Fd[8]);
-                                cnt[h] += __popcll(__ballot(mine && fabs(r) < rcut));
-                            }
-                        }
+                        f32x2 d;
+                        asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(r), "v"(nrc2));
+                        asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(mind[h]) : "v"(d.x), "v"(d.y));   // (a NaN operand is ignored)
+                        bits[h] = __builtin_amdgcn_alignbit(bits[h], __float_as_uint(d.x), 31);      // bits << 1 | sign(d.x)
+                        bits[h] = __builtin_amdgcn_alignbit(bits[h], __float_as_uint(d.y), 31);
                     }
                 }
+                // Turns of this lane that hold no match (beyond N; staged as NaN, which min3 skips) are masked out of the
+                // sign bits: turn k was shifted in k-th, so it sits at bit PPL - 1 - k.  (Non-finite REAL coordinates make
+                // the chunk's band infinite at staging, so every slice of such a chunk is counted in float64 below.)
+                const int nl = N - base - w * 64 - lane;  // > k * 512  <=>  turn k holds a match
+                const int live_turns = max(0, min(PPL, (nl + 64 * SLAM_SLICES - 1) / (64 * SLAM_SLICES)));
+                const unsigned int live_bits = ((1u << live_turns) - 1u) << (PPL - live_turns);
+#pragma unroll
+                for (int h = 0; h < HG; ++h) {
+                    int n = __popc(bits[h] & live_bits);
+                    if (__any(mind[h] < w2[h])) {  // (wave-uniform, rare) some lane is inside the band: the slice again in
+                        ++band_seen;               // float64, as the float64 kernels evaluate it
+                        const double* Fd = Fall + (size_t)min(h0 + h, H - 1) * 9;
+                        const double f0 = Fd[0], f1 = Fd[1], f2 = Fd[2], f3 = Fd[3], f4 = Fd[4], f5 = Fd[5], f6 = Fd[6], f7 = Fd[7],
+                                     f8 = Fd[8];
+                        n = 0;
+#pragma unroll 1
+                        for (int k = 0; k < PPL; ++k) {
+                            const int i = base + k * 64 * SLAM_SLICES + w * 64 + lane;
+                            const double2 a = p0[min(i, N - 1)], b = p1[min(i, N - 1)];
+                            const double r = residual<false>(a.x, a.y, b.x, b.y, f0, f1, f2, f3, f4, f5, f6, f7, f8);
+                            n += (i < N && fabs(r) < rcut) ? 1 : 0;
+                        }
+                    }
+                    cl[h] += n;
+                }
+            }
+            int cnt[HG];  // wave totals
+#pragma unroll
+            for (int h = 0; h < HG; ++h) {
+                int v = cl[h];
+                v += dpp_i32<0xB1>(v);   // lane ^ 1
+                v += dpp_i32<0x4E>(v);   // lane ^ 2
+                v += dpp_i32<0x141>(v);  // 7 - l within 8
+                v += dpp_i32<0x140>(v);  // 15 - l within 16
+                cnt[h] = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+                         __builtin_amdgcn_readlane(v, 48);
             }
             if (lane < HG) {
                 int c = cnt[0];

@@ -47,8 +47,7 @@ __device__ __forceinline__ double rcp_like_division(double x) {
 // homogeneous coordinate small - pass SLAM_TRI_ANGLE_TOL_TIGHT.
 #define SLAM_TRI_ANGLE_TOL_TIGHT 1e-15
 // P0_IS_K_I0: the first camera is K [I|0] (pose recovery): its last column is zero, so rows 0 and 1 of D end in zero.
-//   The zeros are not computed, not scaled and not multiplied through; the Newton iteration of the warm start ends when
-//   the wave has converged (least_right_vector_4x4: Z03, ADAPTIVE_ROOT).
+//   The zeros are not computed, not scaled and not multiplied through (least_right_vector_4x4: Z03).
 template <int MAX_STEPS = SLAM_LEAST4_STEPS, bool P0_IS_K_I0 = false>
 __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, const double* __restrict__ P1, double u0,
                                                 double v0, double u1, double v1, double (&X)[3],
@@ -82,7 +81,7 @@ __device__ __forceinline__ void triangulate_one(const double* __restrict__ P0, c
             if (!(P0_IS_K_I0 && i < 2 && j == 3)) D[i][j] *= im[j];
     // polished until further rotations would turn y by less than 1e-12 rad (the points are compared to 1e-5)
     double yv[4];
-    least_right_vector_4x4<MAX_STEPS, P0_IS_K_I0, P0_IS_K_I0>(D, angle_tol, yv);
+    least_right_vector_4x4<MAX_STEPS, P0_IS_K_I0>(D, angle_tol, yv);
     double Y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Y[i] = m[i] * yv[i];

@@ -607,10 +607,9 @@ __device__ __forceinline__ void rank2_project(const double (&f_in)[9], double (&
 // Z03: the caller guarantees A[0][3] == A[1][3] == 0 (a first camera K [I|0] has a zero last column, so the two rows
 //   of the design matrix that come from it end in zero); the terms they would contribute are left out - the same bits
 //   as with the zeros multiplied through, fewer instructions.
-// ADAPTIVE_ROOT: the Newton iteration for the least root of the characteristic quartic ends as soon as every lane of
-//   the wave has converged (a lane that has converged keeps its value bit for bit while the others go on, so a lane's
-//   result does not depend on its wave mates) instead of always taking SLAM_QUARTIC_NEWTON_STEPS steps.
-template <int MAX_STEPS = SLAM_LEAST4_STEPS, bool Z03 = false, bool ADAPTIVE_ROOT = false>
+// (Ending the Newton iteration of the warm start as soon as the wave has converged was measured and dropped: the loop with
+//   its vote costs more than the steps it saves, here and in the cubic of rank2_project.)
+template <int MAX_STEPS = SLAM_LEAST4_STEPS, bool Z03 = false>
 __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double angle_tol, double (&y)[4]) {
     // (the warm start is written with explicit fma: it only has to be good to a few digits)
     double g[4][4];
@@ -647,29 +646,11 @@ __device__ __forceinline__ void least_right_vector_4x4(double (&A)[4][4], double
                       fma(g[1][1], g[2][2], -g[1][2] * g[1][2]) + fma(g[1][1], g[3][3], -g[1][3] * g[1][3]);
     const double k3 = g[0][0] + g[1][1] + g[2][2] + g[3][3];
     double lam = 0.0;
-    if constexpr (ADAPTIVE_ROOT) {
-        // From 0 the iterates increase monotonically towards the least root (up to rounding), so a step that no longer
-        // moves lam by more than 1e-13 of its value (or of 1e-22 of the trace, for a root that is zero to rounding)
-        // is the last one worth taking: the error after it is the square of that.
-        const double floor_abs = 1e-22 * k3;
-        bool conv = false;
-#pragma unroll 1
-        for (int it = 0; it < SLAM_QUARTIC_NEWTON_STEPS; ++it) {
-            const double p = fma(fma(fma(lam - k3, lam, k2), lam, -k1), lam, k0);
-            const double dp = fma(fma(fma(4.0, lam, -3.0 * k3), lam, k2 + k2), lam, -k1);
-            const double step = -p * __builtin_amdgcn_rcp(dp);
-            const double next = conv ? lam : lam + step;
-            conv = conv || !(fabs(step) > fma(1e-13, fabs(next), floor_abs));  // (true for NaN as well)
-            lam = next;
-            if (!__any(!conv)) break;
-        }
-    } else {
 #pragma unroll
-        for (int it = 0; it < SLAM_QUARTIC_NEWTON_STEPS; ++it) {
-            const double p = fma(fma(fma(lam - k3, lam, k2), lam, -k1), lam, k0);
-            const double dp = fma(fma(fma(4.0, lam, -3.0 * k3), lam, k2 + k2), lam, -k1);
-            lam = fma(-p, __builtin_amdgcn_rcp(dp), lam);  // approximate reciprocal: the iteration self-corrects
-        }
+    for (int it = 0; it < SLAM_QUARTIC_NEWTON_STEPS; ++it) {
+        const double p = fma(fma(fma(lam - k3, lam, k2), lam, -k1), lam, k0);
+        const double dp = fma(fma(fma(4.0, lam, -3.0 * k3), lam, k2 + k2), lam, -k1);
+        lam = fma(-p, __builtin_amdgcn_rcp(dp), lam);  // approximate reciprocal: the iteration self-corrects
     }
     const double d0 = g[0][0] - lam, d1 = g[1][1] - lam, d2 = g[2][2] - lam, d3 = g[3][3] - lam;
     minors(d0, d1, d2, d3);

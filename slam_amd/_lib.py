@@ -78,8 +78,8 @@ SIGNATURES = {
 }
 
 
-SOURCE_FILES = ("slam_amd.hip", "ctx.h", "exchange.h", "linalg.h", "kernels_ransac.h", "kernels_tri.h", "kernels_track.h",
-                "kernels_match.h", "../../include/slam_amd.h")   # the Makefile's $(SRC) $(HDR), in its order
+SOURCE_FILES = ("slam_amd.hip", "ctx.h", "exchange.h", "linalg.h", "kernels_ransac.h", "kernels_count32.h", "kernels_tri.h",
+                "kernels_track.h", "kernels_match.h", "../../include/slam_amd.h")   # the Makefile's $(SRC) $(HDR), in its order
 
 
 def source_hash():

@@ -1015,15 +1015,17 @@ __device__ __forceinline__ void barrier_lds_only() {
 // launches, and it keeps four to eight workgroups busy for as long as a whole scoring kernel.  n_wgs = 0: nothing carried.
 using CarriedSelect = slam_carried_select;  // ctx.h
 
-template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON>
+// CARRY: the kernel can carry a selection (compiled for the large shape only: the small shapes are compiled for five
+// waves per SIMD, 96 registers, and the extra role tips their register allocation into scratch).
+template <int HB, int PPL, int WAVES, int SAMPLER, bool SAMPSON, bool CARRY = (PPL > 4)>
 __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32) / WAVES) void k_ransac(
     // (what the first load of a wave needs comes first: the leading arguments are preloaded into scalar registers)
     const uint32_t* __restrict__ raw, int64_t raw_it0, int64_t it0, int H, int N, const double2* __restrict__ p0,
     const double2* __restrict__ p1, const int32_t* __restrict__ idx_in, uint64_t seed, double rcut,
     double* __restrict__ Fout, int32_t* __restrict__ counts, double* __restrict__ errsums, int32_t* __restrict__ flags,
     const PairArgs* __restrict__ batch, const CarriedSelect carried) {
-    const int n_carried = __builtin_amdgcn_readfirstlane(carried.n_wgs);
-    if ((int)blockIdx.x < n_carried) {  // (uniform per workgroup)
+    const int n_carried = CARRY ? __builtin_amdgcn_readfirstlane(carried.n_wgs) : 0;
+    if (CARRY && (int)blockIdx.x < n_carried) {  // (uniform per workgroup)
         static_assert(WAVES == 8, "the carried selection runs with the fused kernel's 512 threads");
         __shared__ Best s_best[WAVES];
         if (carried.sampson)

@@ -18,10 +18,9 @@
 namespace slamk {
 // The context's error flags live in page-locked host memory that the device writes directly (never, in practice: the
 // one flag says that a sampler ran out of pre-generated words), so that the host reads them after a synchronisation
-// without a copy.  System scope: the word is host memory.
-__device__ __forceinline__ void raise_flag(int32_t* flags) {
-    __hip_atomic_fetch_or(&flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// without a copy.  A plain store of the only value the word ever takes: nothing is read back, so no atomic has to
+// cross the host link.
+__device__ __forceinline__ void raise_flag(int32_t* flags) { *(volatile int32_t*)flags = 1; }
 #ifdef SLAM_STAMPS
 __device__ unsigned long long g_dbg[8];  // sweep statistics of the rank-2 projection; counted only with SLAM_COUNT_SWEEPS
 #endif

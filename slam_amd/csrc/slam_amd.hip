@@ -788,7 +788,8 @@ extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double
     // caller-supplied stream, or n = 1 (the default), every call stays on one stream, in order.
     int lane = 0;
     if (ctx->stream == ctx->own_stream && ctx->lanes_in_use > 1) lane = (int)(ctx->next_lane++ % (unsigned)ctx->lanes_in_use);
-    if (ctx->stream == ctx->own_stream && ctx->lanes_in_use > 1 && H <= SLAM_FUSED_MAX_H && !d_counts && !d_errsums &&
+    // (the fused kernel of the large shape, N > 2048, is the one compiled with the carrying role)
+    if (ctx->stream == ctx->own_stream && ctx->lanes_in_use > 1 && H <= SLAM_FUSED_MAX_H && N > 2048 && !d_counts && !d_errsums &&
         !d_F_all && !ctx->profiling && ctx->carry_selection)
         return ransac_carry(ctx, lane, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask);
     SLAM_TRY(flush_lane(ctx, lane));  // a selection that waits on this lane goes before this call's kernels

@@ -311,21 +311,50 @@ def main():
                     fn()
                 ctx.check(lib.slam_synchronize(ctx.handle))
 
-        settle(big_step)
-        barrier()
-        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
-        ctx.check(lib.slam_profile_reset(ctx.handle))
-        t0 = time.perf_counter()
-        for _ in range(50):
-            big_step()
-        bdt = (stop_clock() - t0) / 50
+        d_es_big = torch.empty(HL, dtype=torch.float64, device=dev)
+        def big_step64():
+            """The same call with the per-hypothesis error sums asked for: that keeps it on the float64 scoring kernel."""
+            ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None,
+                                            _lib.SAMPLER_COUNTER, 3, 0, HL, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(),
+                                            d_mask.data_ptr(), None, d_es_big.data_ptr(), None))
+
+        def timed_score_kernel(fn, calls=50):
+            settle(fn)
+            barrier()
+            ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+            ctx.check(lib.slam_profile_reset(ctx.handle))
+            t0_ = time.perf_counter()
+            for _ in range(calls):
+                fn()
+            per_call = (stop_clock() - t0_) / calls
+            ms_, n_ = C.c_double(0), C.c_int64(0)
+            ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms_), C.byref(n_)))
+            ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+            return per_call, ms_.value / max(n_.value, 1) * 1e3
+
         ms, n = C.c_double(0), C.c_int64(0)
-        ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms), C.byref(n)))
-        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
-        sc_us = ms.value / max(n.value, 1) * 1e3
+        bdt, c32_us = timed_score_kernel(big_step)       # float32 counting, float64 re-check and tie scoring
+        rec32 = d_rec.cpu().numpy().copy()
+        bdt64, sc_us = timed_score_kernel(big_step64)    # float64 scoring of every residual
+        rec64 = d_rec.cpu().numpy()
+        assert np.array_equal(rec32, rec64), "float32 counting and float64 scoring chose different records"
         tfl = FLOP_PER_EVAL * HL * N_MATCHES / (sc_us * 1e-6) / 1e12
-        out["aux_large_h"] = {"workload": "same pair, 65536 hypotheses (counter-based sampler), split solve/score/select path",
+        tfl32 = FLOP_PER_EVAL * HL * N_MATCHES / (c32_us * 1e-6) / 1e12
+        out["aux_large_h"] = {"workload": "same pair, 65536 hypotheses (counter-based sampler), split solve/score/select path; "
+                                          "counts in packed float32 with a float64 re-check band (the default of calls this long "
+                                          "that do not ask for error sums), and the float64 scoring kernel beside it",
                               "hypotheses_per_sec": HL / bdt, "residual_evals_per_sec": HL * N_MATCHES / bdt,
+                              "ms_per_call": bdt * 1e3,
+                              "float64_scoring": {"hypotheses_per_sec": HL / bdt64, "residual_evals_per_sec": HL * N_MATCHES / bdt64,
+                                                  "ms_per_call": bdt64 * 1e3},
+                              "records_identical": True,
+                              "roofline_f32_counts": {"kernel": "k_count_f32", "bound": "mfma", "bound_unit": "valu_fp32_packed",
+                                                      "bound_detail": "packed float32 vector FMAs (v_pk_fma_f32); the peak is the chip's "
+                                                                      "packed FP32 vector rate, no matrix-core work",
+                                                      "achieved": tfl32, "peak": PEAK_FP32_VALU, "unit": "TFLOP/s",
+                                                      "frac": tfl32 / PEAK_FP32_VALU, "traffic": traffic_file.get("k_count_f32_bytes_per_launch"),
+                                                      "algorithmic_bytes_per_launch": N_MATCHES * 32 + HL * 36 + HL * 4,
+                                                      "avg_launch_us": c32_us},
                               "roofline": {"kernel": "k_score_lds", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
                                            "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": tfl / PEAK_FP32_VALU,
                                            "traffic": traffic_file.get("k_score_lds_bytes_per_launch"),

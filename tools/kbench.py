@@ -19,7 +19,10 @@ def main():
     ap.add_argument("--idx", action="store_true", help="hand in pre-drawn indices")
     ap.add_argument("--sampler", type=int, default=0)
     ap.add_argument("--outliers", type=float, default=0.3)
+    ap.add_argument("--f64", action="store_true", help="keep long calls on the float64 scoring kernel")
     args = ap.parse_args()
+    if args.f64:
+        os.environ["SLAM_AMD_F32_COUNTS"] = "0"   # read when the context is created
     import torch
     from slam_amd import _lib, pipeline, synth
     ctx = _lib.Context(0)

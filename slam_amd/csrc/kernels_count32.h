@@ -23,7 +23,9 @@
 
 #include "kernels_ransac.h"
 
+#ifndef SLAM_F32_BAND
 #define SLAM_F32_BAND 5.0e-7
+#endif
 #define SLAM_F32_ROW 12   // floats per hypothesis in the float32 table: F (9), sum |F_ij| rounded up, two unused
 namespace slamk {
 

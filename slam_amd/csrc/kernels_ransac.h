@@ -570,13 +570,16 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
                                                  int h0, int H, int32_t* __restrict__ counts,
                                                  double* __restrict__ errsums, double (*s_part)[WAVES][64],
                                                  int (*s_cnt)[WAVES]) {
-    static_assert((HB == 8 || HB == 4) && WAVES == SLAM_SLICES, "wave j folds hypothesis j; the slices are the eight waves");
+    static_assert((HB == 16 || HB == 8 || HB == 4) && WAVES == SLAM_SLICES, "wave j folds hypotheses j, j + 8; the slices are the eight waves");
     constexpr int THREADS = 64 * WAVES;
+    constexpr int ROUNDS = HB > WAVES ? HB / WAVES : 1;  // hypotheses a wave folds
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // (the lane number is recomputed where it is needed instead of being kept in a register across the loop)
     const unsigned long long full_exec = __ballot(true);  // every lane of the workgroup is active here
-    double total = 0.0;   // of hypothesis `wave`, over the chunks so far (the same on every lane)
-    int ctotal = 0;
+    double total[ROUNDS];   // of hypotheses `wave`, `wave + 8`, over the chunks so far (the same on every lane)
+    int ctotal[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) { total[r] = 0.0; ctotal[r] = 0; }
     // m holds the first chunk on entry and is refilled for the following ones
     for (int base = 0; base < N; base += THREADS * PPL) {
         if (base > 0) {
@@ -651,26 +654,34 @@ __device__ __forceinline__ void score_hypotheses(const double2* __restrict__ p0,
         __syncthreads();
         SLAM_STAMP(5);
         SLAM_STAMP_W8(2);
-        // hypothesis `wave`: the slices in order on every lane position, then the tree over the lane positions
-        // (with fewer hypotheses than waves the surplus waves fold the last one again; their result is dropped)
-        const int hw = HB < WAVES ? min(wave, HB - 1) : wave;
-        double pw[WAVES];
+        // hypothesis `wave` (and `wave + 8` of sixteen): the slices in order on every lane position, then the tree over
+        // the lane positions (with fewer hypotheses than waves the surplus waves fold the last one again; their result
+        // is dropped)
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) pw[w] = s_part[hw][w][lane];
-        int c = 0;
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int hw = HB < WAVES ? min(wave, HB - 1) : wave + r * WAVES;
+            double pw[WAVES];
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) c += s_cnt[hw][w];
-        double t = pw[0];
+            for (int w = 0; w < WAVES; ++w) pw[w] = s_part[hw][w][lane];
+            int c = 0;
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) t += pw[w];
-        total += wave_sum_f64(t);
-        ctotal += c;
+            for (int w = 0; w < WAVES; ++w) c += s_cnt[hw][w];
+            double t = pw[0];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) t += pw[w];
+            total[r] += wave_sum_f64(t);
+            ctotal[r] += c;
+        }
         SLAM_STAMP_W8(3);
     }
     const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (lane == 0 && wave < HB && h0 + wave < H) {
-        counts[h0 + wave] = ctotal;
-        errsums[h0 + wave] = total;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int hw = wave + r * WAVES;
+        if (lane == 0 && hw < HB && h0 + hw < H) {
+            counts[h0 + hw] = ctotal[r];
+            errsums[h0 + hw] = total[r];
+        }
     }
 }
 
@@ -1044,7 +1055,9 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
         p0 = a.n0; p1 = a.n1; N = a.N; H = a.H; Fout = a.F_all; counts = a.counts; errsums = a.errsums;
         if (wg_index * HB >= H) return;  // the grid is sized for the pair with most hypotheses
     }
-    static_assert((HB == 8 || HB == 4) && HB <= WAVES, "one sampling wave per hypothesis; wave 0 solves the hypotheses, eight lanes each");
+    static_assert(HB == 16 || HB == 8 || HB == 4, "a wave draws hypotheses w, w + 8; a solving wave takes eight hypotheses, eight lanes each");
+    constexpr int ROUNDS = HB > WAVES ? HB / WAVES : 1;  // hypotheses a wave draws
+    constexpr int SOLVERS = HB > 8 ? HB / 8 : 1;         // waves that solve
     __shared__ double s_F[HB][9];
     __shared__ double s_part[HB][WAVES][64];  // partial sums p(w,l) of the eight hypotheses
     __shared__ int s_cnt[HB][WAVES];
@@ -1057,14 +1070,18 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
     SLAM_WALL_STAMP(0);
     SLAM_STAMP(0);
     SLAM_WG_LOG_BEGIN();
-    const int hs = min(h0 + min(wave, HB - 1), H - 1);  // surplus waves redo a hypothesis; their results are dropped
-    uint32_t word = 0;
-    if (SAMPLER == SLAM_SAMPLER_CPYTHON) word = raw[(size_t)(it0 + hs - raw_it0) * SLAM_RAW_WORDS + lane];
-    if (wave < HB) {
-        const bool ok = indices_for_wave<SAMPLER>(hs, N, word, idx_in, seed, it0, raw, raw_it0,
-                                                  s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * wave : 0),
-                                                  s_scratch[wave], s_sel[wave]);
-        if (!ok && lane == 0) raise_flag(flags);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int hl = wave + r * WAVES;                  // hypothesis of the workgroup this wave draws now
+        const int hs = min(h0 + min(hl, HB - 1), H - 1);  // surplus waves redo a hypothesis; their results are dropped
+        uint32_t word = 0;
+        if (SAMPLER == SLAM_SAMPLER_CPYTHON) word = raw[(size_t)(it0 + hs - raw_it0) * SLAM_RAW_WORDS + lane];
+        if (hl < HB) {
+            const bool ok = indices_for_wave<SAMPLER>(hs, N, word, idx_in, seed, it0, raw, raw_it0,
+                                                      s_pool + (SAMPLER == SLAM_SAMPLER_CPYTHON ? SLAM_POOL_MAX * hl : 0),
+                                                      s_scratch[hl], s_sel[hl]);
+            if (!ok && lane == 0) raise_flag(flags);
+        }
     }
     barrier_lds_only();
     SLAM_STAMP(1);
@@ -1073,12 +1090,13 @@ __global__ __launch_bounds__(64 * WAVES, (PPL <= 4 ? SLAM_SMALL_SHAPE_WAVES : 32
     // chunk are requested by the other waves now and by wave 0 after its solve: inside the solve they would only
     // hold 64 registers, and with at most 128 two workgroups share a CU - one scores while the other one solves.
     MatchChunk<PPL, WAVES> first;
-    if (wave == 0) {
-        const int g = (lane >> 3) & (HB - 1), c = lane & 7;  // (with four hypotheses the upper half of the wave repeats them)
+    if (wave < SOLVERS) {
+        // (with four hypotheses the upper half of the wave repeats them; with sixteen, waves 0 and 1 take eight each)
+        const int g = HB > 8 ? wave * 8 + (lane >> 3) : (lane >> 3) & (HB - 1), c = lane & 7;
         const int i = min(max(s_sel[g][c], 0), N - 1);  // never read outside the arrays, whatever idx holds
         double F[9];
         solve8_by_eight_lanes(p0[i], p1[i], F);
-        if (c == 0 && lane < 8 * HB) {
+        if (c == 0 && (HB >= 8 || lane < 8 * HB)) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) s_F[g][q] = F[q];
             if (h0 + g < H) {

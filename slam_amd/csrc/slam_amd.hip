@@ -94,6 +94,8 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     if (const char* inject = getenv("SLAM_AMD_FAULT_INJECT")) ctx->inject_sampler_fault = !strcmp(inject, "sampler");
     // SLAM_AMD_F32_COUNTS=0: long calls count in float64 as well (kernels_count32.h is not used)
     if (const char* c = getenv("SLAM_AMD_F32_COUNTS")) ctx->f32_counts = strcmp(c, "0") != 0;
+    // SLAM_AMD_WIDE_WORKGROUPS=0: eight hypotheses per workgroup of the fused kernel also with several calls in flight
+    if (const char* c = getenv("SLAM_AMD_WIDE_WORKGROUPS")) ctx->wide_workgroups = strcmp(c, "0") != 0;
     // SLAM_AMD_CARRY_SELECTION=0: every call launches its own selection kernel also with several calls in flight
     if (const char* c = getenv("SLAM_AMD_CARRY_SELECTION")) ctx->carry_selection = strcmp(c, "0") != 0;
     if ((e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio)) != hipSuccess)
@@ -447,6 +449,16 @@ static int launch_fused(slam_ctx* ctx, const double2* p0, const double2* p1, int
                        it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr, carried)
         SLAM_DISPATCH_SHAPE(N, SLAM_CALL);
 #undef SLAM_CALL
+    }
+    // Sixteen per workgroup with several calls in flight (large shape): a workgroup then spends two thirds of its life
+    // scoring instead of half of it, and of the two workgroups a CU holds (of two different calls) one is scoring more
+    // often.  A call on its own is slower that way (half the CUs, twice the scoring per workgroup).
+    // (the reference's residual only: with the Sampson distance this shape does not fit 128 registers)
+    if constexpr (!SAMPSON)
+    if (ctx->wide_workgroups && ctx->lanes_in_use > 1 && N > 2048 && (H + 15) / 16 >= ctx->num_cus / 2) {
+        const dim3 grid((H + 15) / 16 + carried.n_wgs);
+        return slam_launch(ctx, SLAM_K_SCORE, k_ransac<16, 8, 8, SAMPLER, SAMPSON>, grid, dim3(512), 0, raw, ctx->raw_it0,
+                           it0, H, N, p0, p1, d_idx, seed, thr, F, counts, errsums, flags, (const PairArgs*)nullptr, carried);
     }
     const dim3 grid((H + SLAM_HB - 1) / SLAM_HB + carried.n_wgs);
 #define SLAM_CALL(PPL, WAVES)                                                                                         \

@@ -496,6 +496,44 @@ def test_carried_selections_equal_separate_launches(ctx):
         ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
 
 
+@pytest.mark.parametrize("N,H,sampler", [(4096, 2048, 0), (4096, 2050, 1), (3000, 2063, 1), (9000, 4096, 0), (2049, 4000, 1)])
+def test_sixteen_hypotheses_per_workgroup_equal_eight(ctx, N, H, sampler):
+    """With several calls in flight the fused kernel gives a workgroup sixteen hypotheses instead of eight (large shape):
+    every hypothesis' F, count and error sum, the record and the mask stay bit for bit those of a call on its own,
+    also with a ragged last workgroup (H not a multiple of 16) and ragged or several chunks of matches."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    d = synth.make_pair(N, 0.3, seed=N + H)
+    n0, _ = so.normalize_points(d["pts0"])
+    n1, _ = so.normalize_points(d["pts1"])
+    p0, p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+    smp = _lib.SAMPLER_CPYTHON if sampler == 0 else _lib.SAMPLER_COUNTER
+
+    def run(lanes):
+        ctx.check(lib.slam_set_concurrency(ctx.handle, lanes))
+        rec = torch.full((_lib.REC_LEN,), -3.0, dtype=torch.float64, device=dev)
+        mask = torch.full((N,), 9, dtype=torch.uint8, device=dev)
+        counts = torch.full((H,), -1, dtype=torch.int32, device=dev)
+        errsums = torch.full((H,), -1.0, dtype=torch.float64, device=dev)
+        F = torch.full((H, 9), -1.0, dtype=torch.float64, device=dev)
+        for _ in range(2):  # (the second call of a pair lands on another internal stream)
+            ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, smp, _lib.SEED_BASE, 0, H,
+                                            _lib.DEFAULT_THRESHOLD, rec.data_ptr(), mask.data_ptr(), counts.data_ptr(),
+                                            errsums.data_ptr(), F.data_ptr()))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        return [t.cpu().numpy() for t in (rec, mask, counts, errsums, F)]
+
+    try:
+        want = run(1)
+        got = run(4)
+    finally:
+        ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
+    for w, g, name in zip(want, got, ("record", "mask", "counts", "errsums", "F")):
+        assert np.array_equal(w, g), name
+    assert want[2].min() >= 0 and want[0][_lib.REC_COUNT] == want[2].max() == want[1].sum()
+
+
 @pytest.mark.parametrize("N,H,outliers,scale", [(4096, 65536, 0.3, 1.0), (65536, 8192, 0.7, 1.0), (3000, 50000, 0.5, 1.0),
                                                  (1500, 100000, 0.3, 1.0), (4096, 40000, 0.3, 37.0), (9001, 20000, 0.1, 1e-3)])
 def test_float32_counts_equal_float64_scoring(ctx, N, H, outliers, scale):

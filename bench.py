@@ -269,7 +269,14 @@ def main():
     # taken with the build that is loaded now
     traffic_file, traffic_why = load_traffic(_lib.build_hash())
     traffic = traffic_file.get("k_ransac_bytes_per_launch")
-    roofline = {"kernel": "k_ransac (sample+solve+score)", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": achieved, "peak": PEAK_FP64_VALU,
+    step_tfl = FLOP_PER_EVAL * N_HYP * N_MATCHES / (dt / args.steps / world) / 1e12 / world   # per GPU
+    roofline = {"kernel": "k_ransac (sample+solve+score)",
+                "launch_timed": "one call at a time on one stream (eight hypotheses per workgroup); with several calls in flight "
+                                "the library launches the same kernel with sixteen per workgroup and the grids share the CUs, "
+                                "so a launch's own duration no longer says what the chip delivers: at_step_rate does",
+                "at_step_rate": {"achieved": step_tfl, "frac": step_tfl / PEAK_FP64_VALU,
+                                 "definition": "the scoring flops of one step divided by the step period of the headline (ms_per_step)"},
+                "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": achieved, "peak": PEAK_FP64_VALU,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VALU,
                 "traffic": traffic, "traffic_source": traffic_why or traffic_file.get("source"),
                 "avg_launch_us": score_us, "flop_per_launch": FLOP_PER_EVAL * N_HYP * N_MATCHES,

@@ -9,7 +9,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from slam_amd import slam, synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import slam  # noqa: E402  (examples/slam.py)
+from slam_amd import synth  # noqa: E402
 
 seq = synth.make_sequence(3, n_landmarks=1500, n_clutter=300, seed=7)
 frames = [slam.Frame(*f) for f in seq["frames"]]

@@ -1,4 +1,5 @@
-"""The reference driver's `Slam` class (custom_slam.py:118-254) on top of the GPU path.
+"""EXAMPLE, not part of the library: the reference driver's `Slam` class (custom_slam.py:118-254) on top of the GPU
+path.  It shows how an application would call the matcher, the pair pipeline and the tracking step in sequence.
 
 What differs from the reference, and only that: a frame is given as its keypoints and descriptors (``Frame``)
 instead of an image, because ORB detection is OpenCV's and stays with the caller; there is no visualisation thread.
@@ -17,7 +18,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from . import logger, util
+from slam_amd import logger, util
 
 Frame = namedtuple("Frame", ["keypoints", "descriptors"])  # (n,2) float64 pixel positions; (n,32) uint8 or (n,256) bits
 
@@ -31,21 +32,21 @@ class GpuBackend:
         self.tracking_iterations = tracking_iterations
 
     def matches(self, f0, f1):
-        from . import matching
+        from slam_amd import matching
         return matching.matches_between_keypoints(f0.keypoints, f0.descriptors, f1.keypoints, f1.descriptors, ctx=self.ctx)
 
     def initialise(self, img0_points, img1_points, K):
-        from . import pipeline
+        from slam_amd import pipeline
         r = pipeline.initialise_pair(img0_points, img1_points, K, self.iterations, ctx=self.ctx)
         return r["pose"], r["X"], r["mask"]
 
     def pair_from_frames(self, f0, f1, K):
-        from . import pipeline
+        from slam_amd import pipeline
         r = pipeline.frame_pair(f0.keypoints, f0.descriptors, f1.keypoints, f1.descriptors, K, self.iterations, ctx=self.ctx)
         return r["pose"], [r["matched0"], r["matched1"]], r["X"], r["mask"]
 
     def track(self, pose, prev_known, next_known, X_known, prev_all, next_all, K):
-        from . import triangulation
+        from slam_amd import triangulation
         return triangulation.triangulate_pose_from_points_with_ransac(pose, prev_known, next_known, X_known, prev_all,
                                                                       next_all, K, self.tracking_iterations, ctx=self.ctx)
 

@@ -1,4 +1,4 @@
-"""The three steps of the driver loop on the CPU restatement (test infrastructure: the checker for slam_amd.slam)."""
+"""The three steps of the driver loop on the CPU restatement (test infrastructure: the checker for examples/slam.py)."""
 import math
 import os
 import sys

@@ -1,13 +1,16 @@
-"""The driver loop (slam_amd.slam.Slam) against the reference's own Slam object (custom_slam.py:118-254) run on a
+"""The example driver loop (examples/slam.py: Slam) against the reference's own Slam object (custom_slam.py:118-254) run on a
 synthetic three-frame sequence: tests/golden/driver.npz, made by tests/golden/make_golden.py (gen_driver).
 
 CPU: the bookkeeping on the CPU restatement.  GPU: the same object on the library."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
-from slam_amd import logger, slam
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+import slam  # noqa: E402  (examples/slam.py)
+from slam_amd import logger  # noqa: E402
 from _oracle_backend import OracleBackend
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "driver.npz")

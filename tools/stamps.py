@@ -13,11 +13,14 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("SLA
 import torch  # noqa: E402
 from slam_amd import pipeline, synth  # noqa: E402
 
-# usage: stamps.py [N [H [json-file tag]]]   (with a file name: the phase table is also appended to it as one JSON record)
+# usage: stamps.py [N [H [json-file tag [wide]]]]   (with a file name: the phase table is also appended to it as one JSON
+# record; "wide": the context is told that several calls may be in flight, which selects sixteen hypotheses per workgroup
+# at N > 2048 - the calls are still issued one at a time, so that one launch's stamps are read)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 JSON_OUT = sys.argv[3] if len(sys.argv) > 3 else None
 TAG = sys.argv[4] if len(sys.argv) > 4 else "untagged"
+WIDE = len(sys.argv) > 5 and sys.argv[5] == "wide"
 ctx = _lib.Context(0)
 lib = ctx.lib
 dev = torch.device("cuda", 0)
@@ -27,10 +30,15 @@ n1, _ = pipeline.normalize_points(pair["pts1"], ctx=ctx)
 d_p0, d_p1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
 d_rec = torch.zeros(12, dtype=torch.float64, device=dev)
 torch.cuda.synchronize()
+if WIDE:
+    ctx.check(lib.slam_set_concurrency(ctx.handle, 4))
 for _ in range(20):
     ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N, None, 0, _lib.SEED_BASE, 0, H, 0.005,
                                     d_rec.data_ptr(), None, None, None, None))
-nb = min(4095, (H + 7) // 8)
+    if WIDE:
+        ctx.check(lib.slam_synchronize(ctx.handle))
+per_wg = 16 if WIDE and N > 2048 and (H + 15) // 16 >= 128 else 8
+nb = min(4095, (H + per_wg - 1) // per_wg)
 full = np.zeros(4096 * 8, dtype=np.int64)
 lib.slam_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 ctx.check(lib.slam_debug_stamps(ctx.handle, full.ctypes.data, 4096 * 8))
@@ -51,7 +59,7 @@ tot = st[:, -1] - st[:, 0]
 if JSON_OUT:
     import json
     rec = {"tag": TAG, "library": os.path.basename(_lib.LIB_PATH), "build_hash": lib.slam_build_hash().decode(), "N": N, "H": H,
-           "workgroups": int(nb), "unit": "shader cycles, per workgroup (thread 0 stamps)",
+           "hypotheses_per_workgroup": per_wg, "workgroups": int(nb), "unit": "shader cycles, per workgroup (thread 0 stamps)",
            "phases": {nme: {"median": float(np.median(d[:, i])), "p90": float(np.quantile(d[:, i], 0.9)), "max": float(d[:, i].max())}
                       for i, nme in enumerate(["draw", "null vector", "projection", "barrier before scoring", "score", "wave sum", "barrier and fold"])},
            "workgroup_total": {"median": float(np.median(tot)), "max": float(tot.max())},

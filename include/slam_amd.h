@@ -66,8 +66,12 @@ const char* slam_build_hash(void);
 /* use the caller's HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it */
 int slam_set_stream(slam_ctx* ctx, void* hip_stream);
 /* Number of internal streams (1..4, default 1) that successive slam_ransac_f_dev calls rotate over.  With more than
- * one, consecutive calls may run concurrently (one call's selection overlaps the next call's solve): they must be
- * independent of each other, use distinct output buffers, and their outputs are ready only after slam_synchronize().
+ * one, consecutive calls may run concurrently: they must be independent of each other, use distinct output buffers,
+ * and their outputs are ready only after slam_synchronize().  In that mode a call with more than 2048 matches, at most
+ * 4096 hypotheses and no per-hypothesis outputs is ONE kernel launch: its selection (record and mask) is carried out
+ * by the first workgroups of the kernel of the next such call on the same internal stream, or launched by
+ * slam_synchronize (or any other entry point that waits for the context) when no next call comes; its fused kernel
+ * gives a workgroup sixteen hypotheses instead of eight.  Every result is bit for bit that of a call on its own.
  * Ignored while a caller-supplied stream is set.  No counterpart in the reference (it is single-threaded). */
 int slam_set_concurrency(slam_ctx* ctx, int lanes);
 /* Residual the RANSAC entry points score with (slam_ransac_f, slam_ransac_f_dev, slam_ransac_f_adaptive; the pair
@@ -114,7 +118,12 @@ int slam_eightpoint(slam_ctx* ctx, const double* p0, const double* p1, int M, do
 int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, int N, const int32_t* idx, int sampler,
                   uint64_t seed, int64_t it0, int H, double threshold, double* record, uint8_t* mask,
                   int32_t* counts, double* errsums, double* F_all);
-/* same with device pointers, asynchronous on the context's stream */
+/* same with device pointers, asynchronous on the context's stream.
+ * A call with more than 4096 hypotheses and at least 2^27 (hypothesis, match) pairs that scores the reference's
+ * residual and passes d_errsums == NULL counts inliers in packed float32, evaluates every slice of matches that has a
+ * lane near the threshold again in float64, and computes float64 error sums only for the hypotheses that tie on the
+ * largest count: record, mask and counts are bit for bit those of the float64 kernel, which a call that passes
+ * d_errsums takes (environment variable SLAM_AMD_F32_COUNTS=0: always). */
 int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double* d_p1, int N, const int32_t* d_idx,
                       int sampler, uint64_t seed, int64_t it0, int H, double threshold, double* d_record,
                       uint8_t* d_mask, int32_t* d_counts, double* d_errsums, double* d_F_all);

@@ -302,371 +302,395 @@ def main():
            "aux_steady_state": steady, "library_build": _lib.build_hash(),
            "roofline": roofline}
 
+    class aux_section:
+        """An auxiliary workload must not cost the run its headline: an exception inside one is recorded in the line
+        (aux_errors) and on stderr, and the run goes on with the next."""
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, etype, evalue, tb):
+            if etype is None or not issubclass(etype, Exception):
+                return False
+            import traceback
+            out.setdefault("aux_errors", {})[self.name] = f"{etype.__name__}: {evalue}"
+            print(f"bench.py rank {rank}: auxiliary workload {self.name} failed:", file=sys.stderr)
+            traceback.print_exception(etype, evalue, tb, file=sys.stderr)
+            return True
+
     # ---- aux: steady-state scoring rate (large H: solve and launch overheads amortised), and the host-buffer path
     if not args.no_aux:
-        HL = 65536
-        def big_step():
-            ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None,
-                                            _lib.SAMPLER_COUNTER, 3, 0, HL, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(),
-                                            d_mask.data_ptr(), None, None, None))
-        def settle(fn, seconds=0.25):
-            """Run fn back to back for a while: the clocks the chip holds under a kernel's load take tens of
-            milliseconds to settle (a cold 20-call measurement of this kernel reads 10 % slower)."""
-            t_s = time.perf_counter()
-            while time.perf_counter() - t_s < seconds:
-                for _ in range(20):
+        with aux_section("aux_large_h"):
+            HL = 65536
+            def big_step():
+                ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None,
+                                                _lib.SAMPLER_COUNTER, 3, 0, HL, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(),
+                                                d_mask.data_ptr(), None, None, None))
+            def settle(fn, seconds=0.25):
+                """Run fn back to back for a while: the clocks the chip holds under a kernel's load take tens of
+                milliseconds to settle (a cold 20-call measurement of this kernel reads 10 % slower)."""
+                t_s = time.perf_counter()
+                while time.perf_counter() - t_s < seconds:
+                    for _ in range(20):
+                        fn()
+                    ctx.check(lib.slam_synchronize(ctx.handle))
+
+            d_es_big = torch.empty(HL, dtype=torch.float64, device=dev)
+            def big_step64():
+                """The same call with the per-hypothesis error sums asked for: that keeps it on the float64 scoring kernel."""
+                ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None,
+                                                _lib.SAMPLER_COUNTER, 3, 0, HL, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(),
+                                                d_mask.data_ptr(), None, d_es_big.data_ptr(), None))
+
+            def timed_score_kernel(fn, calls=50):
+                settle(fn)
+                barrier()
+                ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+                ctx.check(lib.slam_profile_reset(ctx.handle))
+                t0_ = time.perf_counter()
+                for _ in range(calls):
                     fn()
-                ctx.check(lib.slam_synchronize(ctx.handle))
+                per_call = (stop_clock() - t0_) / calls
+                ms_, n_ = C.c_double(0), C.c_int64(0)
+                ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms_), C.byref(n_)))
+                ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+                return per_call, ms_.value / max(n_.value, 1) * 1e3
 
-        d_es_big = torch.empty(HL, dtype=torch.float64, device=dev)
-        def big_step64():
-            """The same call with the per-hypothesis error sums asked for: that keeps it on the float64 scoring kernel."""
-            ctx.check(lib.slam_ransac_f_dev(ctx.handle, d_p0.data_ptr(), d_p1.data_ptr(), N_MATCHES, None,
-                                            _lib.SAMPLER_COUNTER, 3, 0, HL, _lib.DEFAULT_THRESHOLD, d_rec.data_ptr(),
-                                            d_mask.data_ptr(), None, d_es_big.data_ptr(), None))
-
-        def timed_score_kernel(fn, calls=50):
-            settle(fn)
+            ms, n = C.c_double(0), C.c_int64(0)
+            bdt, c32_us = timed_score_kernel(big_step)       # float32 counting, float64 re-check and tie scoring
+            rec32 = d_rec.cpu().numpy().copy()
+            bdt64, sc_us = timed_score_kernel(big_step64)    # float64 scoring of every residual
+            rec64 = d_rec.cpu().numpy()
+            assert np.array_equal(rec32, rec64), "float32 counting and float64 scoring chose different records"
+            tfl = FLOP_PER_EVAL * HL * N_MATCHES / (sc_us * 1e-6) / 1e12
+            tfl32 = FLOP_PER_EVAL * HL * N_MATCHES / (c32_us * 1e-6) / 1e12
+            out["aux_large_h"] = {"workload": "same pair, 65536 hypotheses (counter-based sampler), split solve/score/select path; "
+                                              "counts in packed float32 with a float64 re-check band (the default of calls this long "
+                                              "that do not ask for error sums), and the float64 scoring kernel beside it",
+                                  "hypotheses_per_sec": HL / bdt, "residual_evals_per_sec": HL * N_MATCHES / bdt,
+                                  "ms_per_call": bdt * 1e3,
+                                  "float64_scoring": {"hypotheses_per_sec": HL / bdt64, "residual_evals_per_sec": HL * N_MATCHES / bdt64,
+                                                      "ms_per_call": bdt64 * 1e3},
+                                  "records_identical": True,
+                                  "roofline_f32_counts": {"kernel": "k_count_f32", "bound": "mfma", "bound_unit": "valu_fp32_packed",
+                                                          "bound_detail": "packed float32 vector FMAs (v_pk_fma_f32); the peak is the chip's "
+                                                                          "packed FP32 vector rate, no matrix-core work",
+                                                          "achieved": tfl32, "peak": PEAK_FP32_VALU, "unit": "TFLOP/s",
+                                                          "frac": tfl32 / PEAK_FP32_VALU, "traffic": traffic_file.get("k_count_f32_bytes_per_launch"),
+                                                          "algorithmic_bytes_per_launch": N_MATCHES * 32 + HL * 36 + HL * 4,
+                                                          "avg_launch_us": c32_us},
+                                  "roofline": {"kernel": "k_score_lds", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
+                                               "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": tfl / PEAK_FP32_VALU,
+                                               "traffic": traffic_file.get("k_score_lds_bytes_per_launch"),
+                                               "algorithmic_bytes_per_launch": N_MATCHES * 32 + HL * 72 + HL * 12,
+                                               "avg_launch_us": sc_us}}
+            # the same 65536 hypotheses scored with the Sampson distance (optional mode, not the reference's residual)
+            ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_SAMPSON))
+            settle(big_step, 0.1)
             barrier()
             ctx.check(lib.slam_profile_enable(ctx.handle, 1))
             ctx.check(lib.slam_profile_reset(ctx.handle))
-            t0_ = time.perf_counter()
-            for _ in range(calls):
-                fn()
-            per_call = (stop_clock() - t0_) / calls
-            ms_, n_ = C.c_double(0), C.c_int64(0)
-            ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms_), C.byref(n_)))
+            t0 = time.perf_counter()
+            for _ in range(10):
+                big_step()
+            sdt_ = (stop_clock() - t0) / 10
+            ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms), C.byref(n)))
             ctx.check(lib.slam_profile_enable(ctx.handle, 0))
-            return per_call, ms_.value / max(n_.value, 1) * 1e3
-
-        ms, n = C.c_double(0), C.c_int64(0)
-        bdt, c32_us = timed_score_kernel(big_step)       # float32 counting, float64 re-check and tie scoring
-        rec32 = d_rec.cpu().numpy().copy()
-        bdt64, sc_us = timed_score_kernel(big_step64)    # float64 scoring of every residual
-        rec64 = d_rec.cpu().numpy()
-        assert np.array_equal(rec32, rec64), "float32 counting and float64 scoring chose different records"
-        tfl = FLOP_PER_EVAL * HL * N_MATCHES / (sc_us * 1e-6) / 1e12
-        tfl32 = FLOP_PER_EVAL * HL * N_MATCHES / (c32_us * 1e-6) / 1e12
-        out["aux_large_h"] = {"workload": "same pair, 65536 hypotheses (counter-based sampler), split solve/score/select path; "
-                                          "counts in packed float32 with a float64 re-check band (the default of calls this long "
-                                          "that do not ask for error sums), and the float64 scoring kernel beside it",
-                              "hypotheses_per_sec": HL / bdt, "residual_evals_per_sec": HL * N_MATCHES / bdt,
-                              "ms_per_call": bdt * 1e3,
-                              "float64_scoring": {"hypotheses_per_sec": HL / bdt64, "residual_evals_per_sec": HL * N_MATCHES / bdt64,
-                                                  "ms_per_call": bdt64 * 1e3},
-                              "records_identical": True,
-                              "roofline_f32_counts": {"kernel": "k_count_f32", "bound": "mfma", "bound_unit": "valu_fp32_packed",
-                                                      "bound_detail": "packed float32 vector FMAs (v_pk_fma_f32); the peak is the chip's "
-                                                                      "packed FP32 vector rate, no matrix-core work",
-                                                      "achieved": tfl32, "peak": PEAK_FP32_VALU, "unit": "TFLOP/s",
-                                                      "frac": tfl32 / PEAK_FP32_VALU, "traffic": traffic_file.get("k_count_f32_bytes_per_launch"),
-                                                      "algorithmic_bytes_per_launch": N_MATCHES * 32 + HL * 36 + HL * 4,
-                                                      "avg_launch_us": c32_us},
-                              "roofline": {"kernel": "k_score_lds", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": tfl, "peak": PEAK_FP64_VALU,
-                                           "unit": "TFLOP/s", "frac": tfl / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": tfl / PEAK_FP32_VALU,
-                                           "traffic": traffic_file.get("k_score_lds_bytes_per_launch"),
-                                           "algorithmic_bytes_per_launch": N_MATCHES * 32 + HL * 72 + HL * 12,
-                                           "avg_launch_us": sc_us}}
-        # the same 65536 hypotheses scored with the Sampson distance (optional mode, not the reference's residual)
-        ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_SAMPSON))
-        settle(big_step, 0.1)
-        barrier()
-        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
-        ctx.check(lib.slam_profile_reset(ctx.handle))
-        t0 = time.perf_counter()
-        for _ in range(10):
-            big_step()
-        sdt_ = (stop_clock() - t0) / 10
-        ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_SCORE, C.byref(ms), C.byref(n)))
-        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
-        ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_ALGEBRAIC))
-        out["aux_large_h"]["sampson_mode"] = {"sampson_evals_per_sec": HL * N_MATCHES / sdt_,
-                                              "k_score_us": ms.value / max(n.value, 1) * 1e3,
-                                              "k_score_sampson_evals_per_sec": HL * N_MATCHES / (ms.value / max(n.value, 1) * 1e-3)}
-        # host-buffer entry point (what the Python drop-in pays): upload, run, download, synchronise
-        from slam_amd import epipolar
-        epipolar.ransac_detailed(n0, n1, N_HYP, ctx=ctx)
-        t0 = time.perf_counter()
-        for _ in range(200):
+            ctx.check(lib.slam_set_scoring(ctx.handle, _lib.SCORE_ALGEBRAIC))
+            out["aux_large_h"]["sampson_mode"] = {"sampson_evals_per_sec": HL * N_MATCHES / sdt_,
+                                                  "k_score_us": ms.value / max(n.value, 1) * 1e3,
+                                                  "k_score_sampson_evals_per_sec": HL * N_MATCHES / (ms.value / max(n.value, 1) * 1e-3)}
+            # host-buffer entry point (what the Python drop-in pays): upload, run, download, synchronise
+            from slam_amd import epipolar
             epipolar.ransac_detailed(n0, n1, N_HYP, ctx=ctx)
-        hdt = (time.perf_counter() - t0) / 200
-        out["aux_host_path"] = {"workload": "slam_ransac_f on host buffers (PCIe and Python call overhead included)",
-                                "ms_per_call": hdt * 1e3, "hypotheses_per_sec": N_HYP / hdt}
+            t0 = time.perf_counter()
+            for _ in range(200):
+                epipolar.ransac_detailed(n0, n1, N_HYP, ctx=ctx)
+            hdt = (time.perf_counter() - t0) / 200
+            out["aux_host_path"] = {"workload": "slam_ransac_f on host buffers (PCIe and Python call overhead included)",
+                                    "ms_per_call": hdt * 1e3, "hypotheses_per_sec": N_HYP / hdt}
 
     # ---- aux: configuration 3 shape, hypothesis ranges sharded over the ranks, winners exchanged over RCCL
     if not args.no_aux:
-        N3, H3 = 65536, 1 << 20            # the full configuration: 6.9e10 residual evaluations per call
-        pair3 = synth.make_pair(N3, 0.7, seed=3)                     # the same pair on every rank
-        m0, _ = pipeline.normalize_points(pair3["pts0"], ctx=ctx)
-        m1, _ = pipeline.normalize_points(pair3["pts1"], ctx=ctx)
-        e_p0, e_p1 = torch.from_numpy(m0).to(dev), torch.from_numpy(m1).to(dev)
-        e_rec = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
-        lo, hi = pipeline.shard_range(H3, rank, world)
-        torch.cuda.synchronize()
+        with aux_section("aux_hypothesis_sharded"):
+            N3, H3 = 65536, 1 << 20            # the full configuration: 6.9e10 residual evaluations per call
+            pair3 = synth.make_pair(N3, 0.7, seed=3)                     # the same pair on every rank
+            m0, _ = pipeline.normalize_points(pair3["pts0"], ctx=ctx)
+            m1, _ = pipeline.normalize_points(pair3["pts1"], ctx=ctx)
+            e_p0, e_p1 = torch.from_numpy(m0).to(dev), torch.from_numpy(m1).to(dev)
+            e_rec = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+            lo, hi = pipeline.shard_range(H3, rank, world)
+            torch.cuda.synchronize()
 
-        # The library's own communicator (RCCL, one rank per GPU; a single rank when there is one GPU), set up after
-        # the headline measurement so that its streams do not take part in that.
-        pipeline.comm_init(ctx, rank, world)
-        n_comm = C.c_int(0)
-        ctx.check(lib.slam_comm_count(ctx.handle, None, C.byref(n_comm)))
-        # (one line per rank on stderr: the tail of a multi-GPU run shows how many ranks RCCL itself saw)
-        print(f"bench.py rank {rank}: world={world} local_rank={local} device={torch.cuda.get_device_name(local)} "
-              f"rccl_comm_count={n_comm.value}", file=sys.stderr, flush=True)
-        assert n_comm.value == world, f"RCCL communicator spans {n_comm.value} ranks, expected {world}"
+            # The library's own communicator (RCCL, one rank per GPU; a single rank when there is one GPU), set up after
+            # the headline measurement so that its streams do not take part in that.
+            pipeline.comm_init(ctx, rank, world)
+            n_comm = C.c_int(0)
+            ctx.check(lib.slam_comm_count(ctx.handle, None, C.byref(n_comm)))
+            # (one line per rank on stderr: the tail of a multi-GPU run shows how many ranks RCCL itself saw)
+            print(f"bench.py rank {rank}: world={world} local_rank={local} device={torch.cuda.get_device_name(local)} "
+                  f"rccl_comm_count={n_comm.value}", file=sys.stderr, flush=True)
+            assert n_comm.value == world, f"RCCL communicator spans {n_comm.value} ranks, expected {world}"
 
-        def shard_step():
-            # this rank's range, then the exchange inside the library: all-gather of the 96-byte records and the
-            # merge kernel on the context's stream - nothing returns to the host between the two calls
-            ctx.check(lib.slam_ransac_f_dev(ctx.handle, e_p0.data_ptr(), e_p1.data_ptr(), N3, None, _lib.SAMPLER_COUNTER,
-                                            3, lo, hi - lo, _lib.DEFAULT_THRESHOLD, e_rec.data_ptr(), None, None, None, None))
-            ctx.check(lib.slam_exchange_winner_dev(ctx.handle, None, e_rec.data_ptr()))
+            def shard_step():
+                # this rank's range, then the exchange inside the library: all-gather of the 96-byte records and the
+                # merge kernel on the context's stream - nothing returns to the host between the two calls
+                ctx.check(lib.slam_ransac_f_dev(ctx.handle, e_p0.data_ptr(), e_p1.data_ptr(), N3, None, _lib.SAMPLER_COUNTER,
+                                                3, lo, hi - lo, _lib.DEFAULT_THRESHOLD, e_rec.data_ptr(), None, None, None, None))
+                ctx.check(lib.slam_exchange_winner_dev(ctx.handle, None, e_rec.data_ptr()))
 
-        shard_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(3):
             shard_step()
-        sdt = (stop_clock() - t0) / 3      # three calls queued back to back, one synchronisation at the end
-        barrier()
-        t0 = time.perf_counter()
-        shard_step()
-        sdt_sync = stop_clock() - t0       # one call, synchronised: the latency of a call
-        win = e_rec.cpu().numpy()
-        who = next(g for g in range(world) if pipeline.shard_range(H3, g, world)[0] <= int(win[_lib.REC_INDEX])
-                   < pipeline.shard_range(H3, g, world)[1])
-        if use_dist:
-            t = torch.tensor([sdt, sdt_sync], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sdt, sdt_sync = float(t[0].item()), float(t[1].item())
-            # every rank must hold the same winner
-            chk = torch.from_numpy(win).to(dev)
-            ref = chk.clone()
-            dist.broadcast(ref, 0)
-            same = torch.tensor([1.0 if torch.equal(chk, ref) else 0.0], device=dev)
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            agree = bool(same.item() == 1.0)
-        else:
-            agree = True
-        out["aux_hypothesis_sharded"] = {"workload": f"N={N3} matches, 70% outliers, {H3} hypotheses split into contiguous ranges over "
-                                                     f"{world} GPU(s), counter-based sampler, winners exchanged by slam_exchange_winner_dev "
-                                                     "(RCCL all-gather of 96-byte records + merge kernel, no host round trip)",
-                                         "scaling": "strong", "hypotheses_per_sec": H3 / sdt,
-                                         "residual_evals_per_sec": H3 * N3 / sdt, "ms_per_call_pipelined": sdt * 1e3,
-                                         "ms_per_call_synchronised": sdt_sync * 1e3,
-                                         "winner": {"index": int(win[_lib.REC_INDEX]), "inliers": int(win[_lib.REC_COUNT]),
-                                                    "rank": int(who)}, "all_ranks_agree": agree}
-        del e_p0, e_p1
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                shard_step()
+            sdt = (stop_clock() - t0) / 3      # three calls queued back to back, one synchronisation at the end
+            barrier()
+            t0 = time.perf_counter()
+            shard_step()
+            sdt_sync = stop_clock() - t0       # one call, synchronised: the latency of a call
+            win = e_rec.cpu().numpy()
+            who = next(g for g in range(world) if pipeline.shard_range(H3, g, world)[0] <= int(win[_lib.REC_INDEX])
+                       < pipeline.shard_range(H3, g, world)[1])
+            if use_dist:
+                t = torch.tensor([sdt, sdt_sync], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sdt, sdt_sync = float(t[0].item()), float(t[1].item())
+                # every rank must hold the same winner
+                chk = torch.from_numpy(win).to(dev)
+                ref = chk.clone()
+                dist.broadcast(ref, 0)
+                same = torch.tensor([1.0 if torch.equal(chk, ref) else 0.0], device=dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                agree = bool(same.item() == 1.0)
+            else:
+                agree = True
+            out["aux_hypothesis_sharded"] = {"workload": f"N={N3} matches, 70% outliers, {H3} hypotheses split into contiguous ranges over "
+                                                         f"{world} GPU(s), counter-based sampler, winners exchanged by slam_exchange_winner_dev "
+                                                         "(RCCL all-gather of 96-byte records + merge kernel, no host round trip)",
+                                             "scaling": "strong", "hypotheses_per_sec": H3 / sdt,
+                                             "residual_evals_per_sec": H3 * N3 / sdt, "ms_per_call_pipelined": sdt * 1e3,
+                                             "ms_per_call_synchronised": sdt_sync * 1e3,
+                                             "winner": {"index": int(win[_lib.REC_INDEX]), "inliers": int(win[_lib.REC_COUNT]),
+                                                        "rank": int(who)}, "all_ranks_agree": agree}
+            del e_p0, e_p1
 
     # ---- aux: bulk triangulation + cheirality (configuration 5 shape), points resident in HBM
     if not args.no_aux:
-        NT = args.tri_points
-        big = synth.make_pair(1 << 16, 0.0, seed=5)
-        reps = NT // (1 << 16)
-        p0 = torch.from_numpy(big["pts0"]).to(dev).repeat(reps, 1).contiguous()
-        p1 = torch.from_numpy(big["pts1"]).to(dev).repeat(reps, 1).contiguous()
-        torch.manual_seed(5)
-        p1 += torch.rand_like(p1) * 0.25               # make every correspondence distinct
-        E = np.ascontiguousarray(synth.essential_from_motion(big["R"], big["t"]))
-        K = np.ascontiguousarray(big["K"])
-        d_counts = torch.zeros(4, dtype=torch.int64, device=dev)
-        d_pose = torch.zeros(16, dtype=torch.float64, device=dev)
-        d_X = torch.empty((NT, 3), dtype=torch.float64, device=dev)
-        d_win = torch.zeros(1, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        with aux_section("aux"):
+            NT = args.tri_points
+            big = synth.make_pair(1 << 16, 0.0, seed=5)
+            reps = NT // (1 << 16)
+            p0 = torch.from_numpy(big["pts0"]).to(dev).repeat(reps, 1).contiguous()
+            p1 = torch.from_numpy(big["pts1"]).to(dev).repeat(reps, 1).contiguous()
+            torch.manual_seed(5)
+            p1 += torch.rand_like(p1) * 0.25               # make every correspondence distinct
+            E = np.ascontiguousarray(synth.essential_from_motion(big["R"], big["t"]))
+            K = np.ascontiguousarray(big["K"])
+            d_counts = torch.zeros(4, dtype=torch.int64, device=dev)
+            d_pose = torch.zeros(16, dtype=torch.float64, device=dev)
+            d_X = torch.empty((NT, 3), dtype=torch.float64, device=dev)
+            d_win = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
 
-        def tri_step():
-            ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0.data_ptr(), p1.data_ptr(), NT,
-                                                   d_counts.data_ptr()))
-            # point-sharded semantics: the four counts are summed over the ranks before the winner is picked (RCCL
-            # all-reduce queued by the library between the two kernels)
-            ctx.check(lib.slam_allreduce_counts4_dev(ctx.handle, None, d_counts.data_ptr()))
-            ctx.check(lib.slam_pose_select_dev(ctx.handle, d_counts.data_ptr(), NT, d_pose.data_ptr(), d_X.data_ptr(),
-                                               d_win.data_ptr()))
+            def tri_step():
+                ctx.check(lib.slam_pose_candidates_dev(ctx.handle, _lib.ptr(E), _lib.ptr(K), p0.data_ptr(), p1.data_ptr(), NT,
+                                                       d_counts.data_ptr()))
+                # point-sharded semantics: the four counts are summed over the ranks before the winner is picked (RCCL
+                # all-reduce queued by the library between the two kernels)
+                ctx.check(lib.slam_allreduce_counts4_dev(ctx.handle, None, d_counts.data_ptr()))
+                ctx.check(lib.slam_pose_select_dev(ctx.handle, d_counts.data_ptr(), NT, d_pose.data_ptr(), d_X.data_ptr(),
+                                                   d_win.data_ptr()))
 
-        tri_step()
-        barrier()
-        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
-        ctx.check(lib.slam_profile_reset(ctx.handle))
-        tsteps = 5
-        t0 = time.perf_counter()
-        for _ in range(tsteps):
             tri_step()
-        tdt = stop_clock() - t0
-        ms, n = C.c_double(0), C.c_int64(0)
-        ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_TRIANGULATE, C.byref(ms), C.byref(n)))
-        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
-        if use_dist:
-            t = torch.tensor([tdt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tdt = float(t.item())
-        tri_ms = ms.value / max(n.value, 1)
-        tf = TRI_SOLVES_PER_POINT * NT * TRI_FLOP_PER_SOLVE / (tri_ms * 1e-3) / 1e12
-        out["aux"] = {"metric": "triangulated pts/sec (4 candidates per point, cheirality selection)",
-                      "value": world * NT * tsteps / tdt, "unit": "points/s", "points_per_gpu": NT,
-                      "candidate_triangulations_per_sec": 4 * world * NT * tsteps / tdt,
-                      "cheirality_counts": d_counts.cpu().tolist(),
-                      "roofline": {"kernel": "k_triangulate4", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": tf,
-                                   "peak": PEAK_FP64_VALU, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU,
-                                   "avg_launch_ms": tri_ms, "flop_per_dlt_solve": TRI_FLOP_PER_SOLVE,
-                                   "dlt_solves_per_point": TRI_SOLVES_PER_POINT,
-                                   "hbm_GBps_algorithmic": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9,
-                                   "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM}}
-        del p0, p1, d_X
+            barrier()
+            ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+            ctx.check(lib.slam_profile_reset(ctx.handle))
+            tsteps = 5
+            t0 = time.perf_counter()
+            for _ in range(tsteps):
+                tri_step()
+            tdt = stop_clock() - t0
+            ms, n = C.c_double(0), C.c_int64(0)
+            ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_TRIANGULATE, C.byref(ms), C.byref(n)))
+            ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+            if use_dist:
+                t = torch.tensor([tdt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tdt = float(t.item())
+            tri_ms = ms.value / max(n.value, 1)
+            tf = TRI_SOLVES_PER_POINT * NT * TRI_FLOP_PER_SOLVE / (tri_ms * 1e-3) / 1e12
+            out["aux"] = {"metric": "triangulated pts/sec (4 candidates per point, cheirality selection)",
+                          "value": world * NT * tsteps / tdt, "unit": "points/s", "points_per_gpu": NT,
+                          "candidate_triangulations_per_sec": 4 * world * NT * tsteps / tdt,
+                          "cheirality_counts": d_counts.cpu().tolist(),
+                          "roofline": {"kernel": "k_triangulate4", "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": tf,
+                                       "peak": PEAK_FP64_VALU, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU,
+                                       "avg_launch_ms": tri_ms, "flop_per_dlt_solve": TRI_FLOP_PER_SOLVE,
+                                       "dlt_solves_per_point": TRI_SOLVES_PER_POINT,
+                                       "hbm_GBps_algorithmic": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9,
+                                       "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM}}
+            del p0, p1, d_X
 
     # ---- aux: batched sequence, 100 frame pairs sharded over the ranks, whole initialisation per pair (host buffers)
     if not args.no_aux:
-        from slam_amd import pipeline
-        NP_, NB, IB = 100, 2048, 1000
-        mine = [i for i in range(NP_) if i % world == rank]
-        pdata = [synth.make_pair(NB, 0.3, seed=100 + i) for i in mine]
-        plist = [(d["pts0"], d["pts1"]) for d in pdata]
-        Kb = pdata[0]["K"]
-        pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)           # warm-up (buffers, sampler table)
-        barrier()
-        t0 = time.perf_counter()
-        res = pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)
-        bdt = stop_clock() - t0
-        # the same batch handed over already packed (one array per image side and the row offsets)
-        pk0, pk1 = np.concatenate([a_ for a_, _ in plist]), np.concatenate([b_ for _, b_ in plist])
-        pko = np.arange(len(plist) + 1, dtype=np.int64) * NB
-        pipeline.initialise_pairs_packed(pk0, pk1, pko, Kb, iterations=IB, ctx=ctx)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            packed = pipeline.initialise_pairs_packed(pk0, pk1, pko, Kb, iterations=IB, ctx=ctx)
-        pdt = (time.perf_counter() - t0) / 5
-        # and with the packed inputs and the two large outputs in page-locked memory, output arrays reused
-        pin0, pin1 = ctx.pinned_empty(pk0.shape), ctx.pinned_empty(pk1.shape)
-        pin0[:], pin1[:] = pk0, pk1
-        pout = dict(packed)
-        pout["X"], pout["mask"] = ctx.pinned_empty(packed["X"].shape), ctx.pinned_empty(packed["mask"].shape, np.bool_)
-        pipeline.initialise_pairs_packed(pin0, pin1, pko, Kb, iterations=IB, ctx=ctx, out=pout)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            pinned = pipeline.initialise_pairs_packed(pin0, pin1, pko, Kb, iterations=IB, ctx=ctx, out=pout)
-        qdt = (time.perf_counter() - t0) / 5
-        pinned_same = bool(np.array_equal(pinned["X"], packed["X"]) and np.array_equal(pinned["mask"], packed["mask"]))
-        t0 = time.perf_counter()
-        one = [pipeline.initialise_pair(a_, b_, Kb, iterations=IB, ctx=ctx) for a_, b_ in plist[:10]]
-        sdt = (time.perf_counter() - t0) / 10
-        if use_dist:
-            t = torch.tensor([bdt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            bdt = float(t.item())
-        out["aux_batched_pairs"] = {"workload": f"{NP_} frame pairs (N={NB} matches, 30% outliers, {IB} hypotheses, KITTI intrinsics) "
-                                                f"split over {world} GPU(s); whole initialisation per pair (normalise, RANSAC, "
-                                                "F->E, 4-candidate triangulation, selection), host buffers in and out, one call per rank",
-                                    "scaling": "strong", "ms_per_batch": bdt * 1e3, "pairs_per_sec": NP_ / bdt,
-                                    "ms_per_batch_packed_input_this_rank": pdt * 1e3,
-                                    "ms_per_batch_page_locked_buffers_this_rank": qdt * 1e3, "page_locked_equals_packed": pinned_same,
-                                    "packed_equals_list": bool(np.array_equal(packed["X"], np.concatenate([r_["X"] for r_ in res]))),
-                                    "hypotheses_per_sec": NP_ * IB / bdt, "us_per_pair_single_calls": sdt * 1e6,
-                                    "same_as_single_calls": bool(all(np.array_equal(x["X"], y["X"]) for x, y in zip(res, one))),
-                                    "mean_inliers": float(np.mean([r["record"][_lib.REC_COUNT] for r in res]))}
+        with aux_section("aux_batched_pairs"):
+            from slam_amd import pipeline
+            NP_, NB, IB = 100, 2048, 1000
+            mine = [i for i in range(NP_) if i % world == rank]
+            pdata = [synth.make_pair(NB, 0.3, seed=100 + i) for i in mine]
+            plist = [(d["pts0"], d["pts1"]) for d in pdata]
+            Kb = pdata[0]["K"]
+            pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)           # warm-up (buffers, sampler table)
+            barrier()
+            t0 = time.perf_counter()
+            res = pipeline.initialise_pairs(plist, Kb, iterations=IB, ctx=ctx)
+            bdt = stop_clock() - t0
+            # the same batch handed over already packed (one array per image side and the row offsets)
+            pk0, pk1 = np.concatenate([a_ for a_, _ in plist]), np.concatenate([b_ for _, b_ in plist])
+            pko = np.arange(len(plist) + 1, dtype=np.int64) * NB
+            pipeline.initialise_pairs_packed(pk0, pk1, pko, Kb, iterations=IB, ctx=ctx)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                packed = pipeline.initialise_pairs_packed(pk0, pk1, pko, Kb, iterations=IB, ctx=ctx)
+            pdt = (time.perf_counter() - t0) / 5
+            # and with the packed inputs and the two large outputs in page-locked memory, output arrays reused
+            pin0, pin1 = ctx.pinned_empty(pk0.shape), ctx.pinned_empty(pk1.shape)
+            pin0[:], pin1[:] = pk0, pk1
+            pout = dict(packed)
+            pout["X"], pout["mask"] = ctx.pinned_empty(packed["X"].shape), ctx.pinned_empty(packed["mask"].shape, np.bool_)
+            pipeline.initialise_pairs_packed(pin0, pin1, pko, Kb, iterations=IB, ctx=ctx, out=pout)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                pinned = pipeline.initialise_pairs_packed(pin0, pin1, pko, Kb, iterations=IB, ctx=ctx, out=pout)
+            qdt = (time.perf_counter() - t0) / 5
+            pinned_same = bool(np.array_equal(pinned["X"], packed["X"]) and np.array_equal(pinned["mask"], packed["mask"]))
+            t0 = time.perf_counter()
+            one = [pipeline.initialise_pair(a_, b_, Kb, iterations=IB, ctx=ctx) for a_, b_ in plist[:10]]
+            sdt = (time.perf_counter() - t0) / 10
+            if use_dist:
+                t = torch.tensor([bdt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                bdt = float(t.item())
+            out["aux_batched_pairs"] = {"workload": f"{NP_} frame pairs (N={NB} matches, 30% outliers, {IB} hypotheses, KITTI intrinsics) "
+                                                    f"split over {world} GPU(s); whole initialisation per pair (normalise, RANSAC, "
+                                                    "F->E, 4-candidate triangulation, selection), host buffers in and out, one call per rank",
+                                        "scaling": "strong", "ms_per_batch": bdt * 1e3, "pairs_per_sec": NP_ / bdt,
+                                        "ms_per_batch_packed_input_this_rank": pdt * 1e3,
+                                        "ms_per_batch_page_locked_buffers_this_rank": qdt * 1e3, "page_locked_equals_packed": pinned_same,
+                                        "packed_equals_list": bool(np.array_equal(packed["X"], np.concatenate([r_["X"] for r_ in res]))),
+                                        "hypotheses_per_sec": NP_ * IB / bdt, "us_per_pair_single_calls": sdt * 1e6,
+                                        "same_as_single_calls": bool(all(np.array_equal(x["X"], y["X"]) for x, y in zip(res, one))),
+                                        "mean_inliers": float(np.mean([r["record"][_lib.REC_COUNT] for r in res]))}
 
     # ---- aux: tracking step (pose from 2D-3D matches, 100 hypotheses), inputs resident in HBM
     if not args.no_aux:
-        MK, NA, TI = 300, 1000, 100
-        tr = synth.make_track(MK, NA, 0.3, seed=7)
-        tt = {k: torch.from_numpy(np.ascontiguousarray(tr[k])).to(dev) for k in ("prev_known", "next_known", "X_known", "prev_all", "next_all")}
-        t_pose = torch.empty(16, dtype=torch.float64, device=dev)
-        t_X = torch.empty((NA, 3), dtype=torch.float64, device=dev)
-        t_best = torch.empty(3, dtype=torch.float64, device=dev)
-        prev_pose, Kt = _lib.f64(tr["previous_pose"]), _lib.f64(tr["K"])
-        torch.cuda.synchronize()
+        with aux_section("aux_tracking"):
+            MK, NA, TI = 300, 1000, 100
+            tr = synth.make_track(MK, NA, 0.3, seed=7)
+            tt = {k: torch.from_numpy(np.ascontiguousarray(tr[k])).to(dev) for k in ("prev_known", "next_known", "X_known", "prev_all", "next_all")}
+            t_pose = torch.empty(16, dtype=torch.float64, device=dev)
+            t_X = torch.empty((NA, 3), dtype=torch.float64, device=dev)
+            t_best = torch.empty(3, dtype=torch.float64, device=dev)
+            prev_pose, Kt = _lib.f64(tr["previous_pose"]), _lib.f64(tr["K"])
+            torch.cuda.synchronize()
 
-        def track_step():
-            ctx.check(lib.slam_track_pose_dev(ctx.handle, _lib.ptr(prev_pose), tt["prev_known"].data_ptr(),
-                                              tt["next_known"].data_ptr(), tt["X_known"].data_ptr(), MK,
-                                              tt["prev_all"].data_ptr(), tt["next_all"].data_ptr(), NA, _lib.ptr(Kt), TI,
-                                              t_pose.data_ptr(), t_X.data_ptr(), t_best.data_ptr()))
+            def track_step():
+                ctx.check(lib.slam_track_pose_dev(ctx.handle, _lib.ptr(prev_pose), tt["prev_known"].data_ptr(),
+                                                  tt["next_known"].data_ptr(), tt["X_known"].data_ptr(), MK,
+                                                  tt["prev_all"].data_ptr(), tt["next_all"].data_ptr(), NA, _lib.ptr(Kt), TI,
+                                                  t_pose.data_ptr(), t_X.data_ptr(), t_best.data_ptr()))
 
-        for _ in range(3):
-            track_step()
-        barrier()
-        ksteps = 20
-        t0 = time.perf_counter()
-        for _ in range(ksteps):
-            track_step()
-        kdt = (stop_clock() - t0) / ksteps
-        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
-        ctx.check(lib.slam_profile_reset(ctx.handle))
-        for _ in range(ksteps):
-            track_step()
-        kt = {}
-        for name, kid in (("k_resect", _lib.K_RESECT), ("k_track_score", _lib.K_TRACK_SCORE)):
-            ms, n = C.c_double(0), C.c_int64(0)
-            ctx.check(lib.slam_profile_read(ctx.handle, kid, C.byref(ms), C.byref(n)))
-            kt[name + "_us"] = 1e3 * ms.value / max(n.value, 1)
-        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
-        out["aux_tracking"] = {"workload": f"tracking step: {MK} matches with a known 3D position (30% wrong), {TI} six-point "
-                                           f"hypotheses, {NA} matches triangulated with the winner",
-                               "us_per_step": kdt * 1e6, "steps_per_sec": world / kdt, **kt,
-                               "winner": {"index": int(t_best[0].item()), "in_front": int(t_best[1].item())}}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            from oracle import c_oracle as co
-            tidx = co.sample(MK, TI, k=6)
-            t1 = time.perf_counter()
-            ow = co.tracking_ransac(tr["previous_pose"], tr["prev_known"], tr["next_known"], tr["X_known"], tr["K"], tidx)
-            co.triangulate(tr["previous_pose"], ow["pose"], tr["prev_all"], tr["next_all"])
-            out["aux_tracking"]["cpu_port_us_per_step"] = (time.perf_counter() - t1) * 1e6
-            out["aux_tracking"]["winner_matches_cpu"] = bool(ow["best_index"] == int(t_best[0].item()))
+            for _ in range(3):
+                track_step()
+            barrier()
+            ksteps = 20
+            t0 = time.perf_counter()
+            for _ in range(ksteps):
+                track_step()
+            kdt = (stop_clock() - t0) / ksteps
+            ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+            ctx.check(lib.slam_profile_reset(ctx.handle))
+            for _ in range(ksteps):
+                track_step()
+            kt = {}
+            for name, kid in (("k_resect", _lib.K_RESECT), ("k_track_score", _lib.K_TRACK_SCORE)):
+                ms, n = C.c_double(0), C.c_int64(0)
+                ctx.check(lib.slam_profile_read(ctx.handle, kid, C.byref(ms), C.byref(n)))
+                kt[name + "_us"] = 1e3 * ms.value / max(n.value, 1)
+            ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+            out["aux_tracking"] = {"workload": f"tracking step: {MK} matches with a known 3D position (30% wrong), {TI} six-point "
+                                               f"hypotheses, {NA} matches triangulated with the winner",
+                                   "us_per_step": kdt * 1e6, "steps_per_sec": world / kdt, **kt,
+                                   "winner": {"index": int(t_best[0].item()), "in_front": int(t_best[1].item())}}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                from oracle import c_oracle as co
+                tidx = co.sample(MK, TI, k=6)
+                t1 = time.perf_counter()
+                ow = co.tracking_ransac(tr["previous_pose"], tr["prev_known"], tr["next_known"], tr["X_known"], tr["K"], tidx)
+                co.triangulate(tr["previous_pose"], ow["pose"], tr["prev_all"], tr["next_all"])
+                out["aux_tracking"]["cpu_port_us_per_step"] = (time.perf_counter() - t1) * 1e6
+                out["aux_tracking"]["winner_matches_cpu"] = bool(ow["best_index"] == int(t_best[0].item()))
 
     # ---- aux: descriptor matching (Hamming 2-NN + ratio test + gathering), descriptors resident in HBM
     if not args.no_aux:
-        NQ = NTR = 4096
-        rng = np.random.default_rng(11)
-        des0 = rng.integers(0, 256, (NQ, 32), dtype=np.uint8)
-        des1 = rng.integers(0, 256, (NTR, 32), dtype=np.uint8)
-        bits = np.unpackbits(des0[:NQ // 2], axis=1)
-        for qi in range(NQ // 2):
-            bits[qi, rng.choice(256, 30, replace=False)] ^= 1
-        des1[rng.choice(NTR, NQ // 2, replace=False)] = np.packbits(bits, axis=1)
-        kp0, kp1 = rng.uniform(0, 1000, (NQ, 2)), rng.uniform(0, 1000, (NTR, 2))
-        mt = [torch.from_numpy(x).to(dev) for x in (des0, kp0, des1, kp1)]
-        mm0 = torch.empty((NQ, 2), dtype=torch.float64, device=dev)
-        mm1 = torch.empty((NQ, 2), dtype=torch.float64, device=dev)
-        mn = torch.zeros(1, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        with aux_section("aux_matching"):
+            NQ = NTR = 4096
+            rng = np.random.default_rng(11)
+            des0 = rng.integers(0, 256, (NQ, 32), dtype=np.uint8)
+            des1 = rng.integers(0, 256, (NTR, 32), dtype=np.uint8)
+            bits = np.unpackbits(des0[:NQ // 2], axis=1)
+            for qi in range(NQ // 2):
+                bits[qi, rng.choice(256, 30, replace=False)] ^= 1
+            des1[rng.choice(NTR, NQ // 2, replace=False)] = np.packbits(bits, axis=1)
+            kp0, kp1 = rng.uniform(0, 1000, (NQ, 2)), rng.uniform(0, 1000, (NTR, 2))
+            mt = [torch.from_numpy(x).to(dev) for x in (des0, kp0, des1, kp1)]
+            mm0 = torch.empty((NQ, 2), dtype=torch.float64, device=dev)
+            mm1 = torch.empty((NQ, 2), dtype=torch.float64, device=dev)
+            mn = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
 
-        def match_step():
-            ctx.check(lib.slam_match_points_dev(ctx.handle, mt[0].data_ptr(), mt[1].data_ptr(), NQ, mt[2].data_ptr(),
-                                                mt[3].data_ptr(), NTR, mm0.data_ptr(), mm1.data_ptr(), mn.data_ptr(), None, None))
+            def match_step():
+                ctx.check(lib.slam_match_points_dev(ctx.handle, mt[0].data_ptr(), mt[1].data_ptr(), NQ, mt[2].data_ptr(),
+                                                    mt[3].data_ptr(), NTR, mm0.data_ptr(), mm1.data_ptr(), mn.data_ptr(), None, None))
 
-        for _ in range(3):
-            match_step()
-        barrier()
-        msteps = 50
-        t0 = time.perf_counter()
-        for _ in range(msteps):
-            match_step()
-        mdt_ = (stop_clock() - t0) / msteps
-        ctx.check(lib.slam_profile_enable(ctx.handle, 1))
-        ctx.check(lib.slam_profile_reset(ctx.handle))
-        for _ in range(msteps):
-            match_step()
-        ms, n = C.c_double(0), C.c_int64(0)
-        ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_MATCH, C.byref(ms), C.byref(n)))
-        ctx.check(lib.slam_profile_enable(ctx.handle, 0))
-        k_us = 1e3 * ms.value / max(n.value, 1)
-        pairs = NQ * NTR
-        # issue bound of the inner loop: 20 vector integer instructions per (query, train) pair and lane, one wave
-        # instruction per 4 cycles and SIMD, 1024 SIMDs at 2.4 GHz
-        peak_pairs = 1024 * 2.4e9 / (4 * 20) * 64
-        out["aux_matching"] = {"workload": f"{NQ} x {NTR} 256-bit descriptors: Hamming 2-NN, ratio test, ordered gathering of the kept matches",
-                               "us_per_step": mdt_ * 1e6, "descriptor_pairs_per_sec": world * pairs / mdt_,
-                               "kept_matches": int(mn.item()),
-                               "roofline": {"kernel": "k_match_knn2", "bound": "valu_int", "achieved": pairs / (k_us * 1e-6),
-                                            "peak": peak_pairs, "unit": "descriptor pairs/s", "frac": pairs / (k_us * 1e-6) / peak_pairs,
-                                            "avg_launch_us": k_us, "valu_instructions_per_pair": 20}}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            from oracle import c_oracle as co
-            t1 = time.perf_counter()
-            wi, wd = co.match_knn(des0, des1, 2)
-            w0, w1 = co.select_matches(kp0, kp1, wi, wd)
-            out["aux_matching"]["cpu_port_us_per_step"] = (time.perf_counter() - t1) * 1e6
-            k = int(mn.item())
-            out["aux_matching"]["matches_equal_cpu"] = bool(k == len(w0) and np.array_equal(mm0[:k].cpu().numpy(), w0)
-                                                            and np.array_equal(mm1[:k].cpu().numpy(), w1))
+            for _ in range(3):
+                match_step()
+            barrier()
+            msteps = 50
+            t0 = time.perf_counter()
+            for _ in range(msteps):
+                match_step()
+            mdt_ = (stop_clock() - t0) / msteps
+            ctx.check(lib.slam_profile_enable(ctx.handle, 1))
+            ctx.check(lib.slam_profile_reset(ctx.handle))
+            for _ in range(msteps):
+                match_step()
+            ms, n = C.c_double(0), C.c_int64(0)
+            ctx.check(lib.slam_profile_read(ctx.handle, _lib.K_MATCH, C.byref(ms), C.byref(n)))
+            ctx.check(lib.slam_profile_enable(ctx.handle, 0))
+            k_us = 1e3 * ms.value / max(n.value, 1)
+            pairs = NQ * NTR
+            # issue bound of the inner loop: 20 vector integer instructions per (query, train) pair and lane, one wave
+            # instruction per 4 cycles and SIMD, 1024 SIMDs at 2.4 GHz
+            peak_pairs = 1024 * 2.4e9 / (4 * 20) * 64
+            out["aux_matching"] = {"workload": f"{NQ} x {NTR} 256-bit descriptors: Hamming 2-NN, ratio test, ordered gathering of the kept matches",
+                                   "us_per_step": mdt_ * 1e6, "descriptor_pairs_per_sec": world * pairs / mdt_,
+                                   "kept_matches": int(mn.item()),
+                                   "roofline": {"kernel": "k_match_knn2", "bound": "valu_int", "achieved": pairs / (k_us * 1e-6),
+                                                "peak": peak_pairs, "unit": "descriptor pairs/s", "frac": pairs / (k_us * 1e-6) / peak_pairs,
+                                                "avg_launch_us": k_us, "valu_instructions_per_pair": 20}}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                from oracle import c_oracle as co
+                t1 = time.perf_counter()
+                wi, wd = co.match_knn(des0, des1, 2)
+                w0, w1 = co.select_matches(kp0, kp1, wi, wd)
+                out["aux_matching"]["cpu_port_us_per_step"] = (time.perf_counter() - t1) * 1e6
+                k = int(mn.item())
+                out["aux_matching"]["matches_equal_cpu"] = bool(k == len(w0) and np.array_equal(mm0[:k].cpu().numpy(), w0)
+                                                                and np.array_equal(mm1[:k].cpu().numpy(), w1))
 
     # ---- CPU baseline: the C restatement on this host (rank 0, single GPU runs only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

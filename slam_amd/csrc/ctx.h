@@ -76,6 +76,7 @@ struct slam_ctx {
     size_t carry_set_bytes[SLAM_LANES] = {};
     unsigned carry_turn[SLAM_LANES] = {};
     bool f32_counts = true;                        // SLAM_AMD_F32_COUNTS=0 keeps long calls on the float64 scoring kernel
+    bool report_f32_band = false;                  // SLAM_AMD_REPORT_F32_BAND=1: the float32 counting path prints its band statistics
     bool wide_workgroups = true;                   // SLAM_AMD_WIDE_WORKGROUPS=0: eight hypotheses per workgroup whatever is in flight
     bool carry_selection = true;                   // SLAM_AMD_CARRY_SELECTION=0 turns the carrying off
     slam_carried_select pending[SLAM_LANES] = {};  // n_wgs > 0: a selection waiting to be carried or launched

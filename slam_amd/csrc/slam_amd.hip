@@ -94,6 +94,7 @@ extern "C" int slam_create(int device, slam_ctx** out) {
     if (const char* inject = getenv("SLAM_AMD_FAULT_INJECT")) ctx->inject_sampler_fault = !strcmp(inject, "sampler");
     // SLAM_AMD_F32_COUNTS=0: long calls count in float64 as well (kernels_count32.h is not used)
     if (const char* c = getenv("SLAM_AMD_F32_COUNTS")) ctx->f32_counts = strcmp(c, "0") != 0;
+    if (const char* c = getenv("SLAM_AMD_REPORT_F32_BAND")) ctx->report_f32_band = strcmp(c, "0") != 0;
     // SLAM_AMD_WIDE_WORKGROUPS=0: eight hypotheses per workgroup of the fused kernel also with several calls in flight
     if (const char* c = getenv("SLAM_AMD_WIDE_WORKGROUPS")) ctx->wide_workgroups = strcmp(c, "0") != 0;
     // SLAM_AMD_CARRY_SELECTION=0: every call launches its own selection kernel also with several calls in flight
@@ -587,7 +588,7 @@ static int launch_count_f32(slam_ctx* ctx, const double2* p0, const double2* p1,
     else
         SLAM_TRY(slam_launch(ctx, SLAM_K_SCORE, k_count_f32<SLAM_COUNT_HG, 8, SLAM_SCORE_WAVES>, grid, dim3(64 * SLAM_SCORE_WAVES), 0,
                              p0, p1, N, (const float*)a.F32, (const double*)F, H, rcut, nchunks, nslots, counts, nchunks > 1 ? 1 : 0, a.state));
-    if (getenv("SLAM_AMD_DEBUG_F32")) {  // statistics of the re-check band (diagnostic)
+    if (ctx->report_f32_band) {  // SLAM_AMD_REPORT_F32_BAND=1: statistics of the re-check band on stderr (diagnostic; synchronises)
         CountState hs;
         SLAM_HIP(ctx, hipStreamSynchronize(ctx->cur));
         SLAM_HIP(ctx, hipMemcpy(&hs, a.state, sizeof hs, hipMemcpyDeviceToHost));

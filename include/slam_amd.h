@@ -72,6 +72,8 @@ int slam_set_stream(slam_ctx* ctx, void* hip_stream);
  * by the first workgroups of the kernel of the next such call on the same internal stream, or launched by
  * slam_synchronize (or any other entry point that waits for the context) when no next call comes; its fused kernel
  * gives a workgroup sixteen hypotheses instead of eight.  Every result is bit for bit that of a call on its own.
+ * Every buffer a call names, inputs included, must stay allocated and unchanged until that synchronisation (the carried
+ * selection reads the matches again for the mask).
  * Ignored while a caller-supplied stream is set.  No counterpart in the reference (it is single-threaded). */
 int slam_set_concurrency(slam_ctx* ctx, int lanes);
 /* Residual the RANSAC entry points score with (slam_ransac_f, slam_ransac_f_dev, slam_ransac_f_adaptive; the pair

@@ -531,7 +531,11 @@ def main():
                                        "avg_launch_ms": tri_ms, "flop_per_dlt_solve": TRI_FLOP_PER_SOLVE,
                                        "dlt_solves_per_point": TRI_SOLVES_PER_POINT,
                                        "hbm_GBps_algorithmic": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9,
-                                       "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM}}
+                                       "hbm_frac": NT * TRI_BYTES_PER_POINT / (tri_ms * 1e-3) / 1e9 / PEAK_HBM,
+                                       # counters of a 16 M point launch (quoted when this launch has that size)
+                                       "traffic": traffic_file.get("k_triangulate4_bytes_per_launch") if NT == (1 << 24) else None,
+                                       # what this kernel has to move: the match once (32 B), two candidate planes (2 x 24 B)
+                                       "algorithmic_bytes_per_launch": NT * 80}}
             del p0, p1, d_X
 
     # ---- aux: batched sequence, 100 frame pairs sharded over the ranks, whole initialisation per pair (host buffers)

@@ -627,6 +627,26 @@ def test_config3_full_size_properties(ctx):
     _, win = pipeline.merge_records(parts)
     assert np.array_equal(win, full_rec)
     assert int(mask.sum().item()) == int(full_rec[_lib.REC_COUNT]) == int(full_counts.max())
+    # what the ranks of a sharded run actually execute: the same ranges without per-hypothesis error sums, i.e. counted
+    # in float32 with the float64 re-check band - counts, range winners and the merged winner stay the same bits, and so
+    # does the unsharded call
+    c3 = torch.zeros(H, dtype=torch.int32, device=dev)
+    parts32 = []
+    for g in range(8):
+        lo, hi = pipeline.shard_range(H, g, 8)
+        r = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+        ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 3, lo, hi - lo,
+                                        0.005, r.data_ptr(), None, c3[lo:].data_ptr(), None, None))
+        ctx.check(lib.slam_synchronize(ctx.handle))
+        parts32.append(r.cpu().numpy())
+    assert np.array_equal(c3.cpu().numpy(), full_counts)
+    assert all(np.array_equal(a, b) for a, b in zip(parts32, parts))
+    rec32 = torch.zeros(_lib.REC_LEN, dtype=torch.float64, device=dev)
+    mask32 = torch.zeros(N, dtype=torch.uint8, device=dev)
+    ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, _lib.SAMPLER_COUNTER, 3, 0, H, 0.005,
+                                    rec32.data_ptr(), mask32.data_ptr(), None, None, None))
+    ctx.check(lib.slam_synchronize(ctx.handle))
+    assert np.array_equal(rec32.cpu().numpy(), full_rec) and torch.equal(mask32, mask)
     # a random sample of hypotheses (and the winner) against the C restatement on the same index sets
     pick = np.unique(np.concatenate([np.random.default_rng(1).integers(0, H, 96), [int(full_rec[_lib.REC_INDEX])]]))
     idx = so.sample_indices_counter(N, pick, seed=3)

@@ -254,7 +254,10 @@ def main():
     ctx.check(lib.slam_profile_enable(ctx.handle, 1))
     ctx.check(lib.slam_profile_reset(ctx.handle))
     barrier()
-    for _ in range(args.steps):
+    # (at least 500 launches whatever K is: the average of a handful of launches right after an idle moment reads
+    # 15-20 % shorter than the sustained duration a kernel trace of a whole run reports)
+    roofline_launches = max(args.steps, 500)
+    for _ in range(roofline_launches):
         step()
     barrier()
     kern = {}
@@ -279,7 +282,7 @@ def main():
                 "bound": "mfma", "bound_unit": BOUND_UNIT, "bound_detail": BOUND_DETAIL, "achieved": achieved, "peak": PEAK_FP64_VALU,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU, "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VALU,
                 "traffic": traffic, "traffic_source": traffic_why or traffic_file.get("source"),
-                "avg_launch_us": score_us, "flop_per_launch": FLOP_PER_EVAL * N_HYP * N_MATCHES,
+                "avg_launch_us": score_us, "launches_averaged": roofline_launches, "flop_per_launch": FLOP_PER_EVAL * N_HYP * N_MATCHES,
                 # matches in, per hypothesis 64 sampler words in and F, count, error sum out
                 "algorithmic_bytes_per_launch": N_MATCHES * 32 + N_HYP * (256 + 72 + 12),
                 "other_kernels_us": {"k_select": kern["select"]}}

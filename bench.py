@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--tri-points", type=int, default=1 << 24)
+    ap.add_argument("--aux-timeout", type=float, default=420.0,
+                    help="seconds after which a run whose auxiliary workloads have not finished writes its line and ends")
     ap.add_argument("--lanes", type=int, default=4, help="independent steps the library may keep in flight (1..4)")
     ap.add_argument("--bursts", type=int, default=50, help="timed bursts of --steps steps each; the median burst is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -322,6 +324,31 @@ def main():
             print(f"bench.py rank {rank}: auxiliary workload {self.name} failed:", file=sys.stderr)
             traceback.print_exception(etype, evalue, tb, file=sys.stderr)
             return True
+
+    # The headline is complete at this point.  Everything below is auxiliary, and some of it is collective (the
+    # library's RCCL exchange): should it ever hang - ranks that disagree, a fabric problem - the run would end at the
+    # caller's time limit with no line at all.  A watchdog therefore writes the line with what there is and ends the
+    # process when the auxiliary part takes longer than --aux-timeout seconds.
+    import threading
+    line_written = threading.Lock()
+
+    def write_line_once():
+        if rank == 0 and line_written.acquire(blocking=False):
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out, default=str) + "\n").encode())
+
+    def watchdog_fired():
+        out.setdefault("aux_errors", {})["watchdog"] = (f"the auxiliary workloads did not finish within {args.aux_timeout} s; "
+                                                        "the line holds what had been measured by then")
+        print(f"bench.py rank {rank}: auxiliary workloads exceeded {args.aux_timeout} s, ending the run", file=sys.stderr)
+        try:
+            write_line_once()
+        finally:
+            os._exit(0 if rank == 0 else 3)
+
+    watchdog = threading.Timer(args.aux_timeout, watchdog_fired)
+    watchdog.daemon = True
+    watchdog.start()
 
     # ---- aux: steady-state scoring rate (large H: solve and launch overheads amortised), and the host-buffer path
     if not args.no_aux:
@@ -718,9 +745,8 @@ def main():
                                "winner_matches_gpu": bool(t1c["best_index"] == int(rec[_lib.REC_INDEX])),
                                "reference_python_measured": {"value": 80.0, "unit": "hypotheses/s", "cores": 1}}
 
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    watchdog.cancel()
+    write_line_once()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -152,6 +152,8 @@ extern "C" void slam_destroy(slam_ctx* ctx) {
     }
     for (hipEvent_t ev : ctx->lane_event)
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->sync_event)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -721,6 +723,7 @@ static int flush_lane(slam_ctx* ctx, int l) {
     if (c.n_wgs == 0) return SLAM_OK;
     hipStream_t keep = ctx->cur;
     ctx->cur = ctx->lane_stream[l];
+    ctx->lanes_dirty |= 1u << l;
     int rc;
     if (c.sampson)
         rc = slam_launch(ctx, SLAM_K_SELECT, k_select<true>, select_grid(c.N, c.mask), dim3(SLAM_SELECT_THREADS), 0, c.counts,
@@ -774,6 +777,7 @@ static int ransac_carry(slam_ctx* ctx, int lane, const double* d_p0, const doubl
     const double cut = ctx->sampson ? thr : square_cutoff(thr);
     const CarriedSelect carried = ctx->pending[lane];  // n_wgs == 0: nothing to carry
     ctx->cur = ctx->lane_stream[lane];
+    ctx->lanes_dirty |= 1u << lane;
     int rc;
 #define SLAM_CARRY(SAMPLER_ID, IDX)                                                                                        \
     rc = ctx->sampson ? launch_fused<SAMPLER_ID, true>(ctx, p0, p1, N, IDX, seed, it0, H, cut, F, counts, errsums, carried) \
@@ -814,6 +818,7 @@ extern "C" int slam_ransac_f_dev(slam_ctx* ctx, const double* d_p0, const double
     double* const caller_errsums = d_errsums;
     if (lane > 0 && !d_errsums) { SLAM_TRY(slam_reserve(ctx, ctx->lane_errsums[lane], (size_t)H * sizeof(double))); d_errsums = (double*)ctx->lane_errsums[lane].p; }
     ctx->cur = ctx->lane_stream[lane] && ctx->stream == ctx->own_stream ? ctx->lane_stream[lane] : ctx->stream;
+    if (ctx->cur != ctx->stream) ctx->lanes_dirty |= 1u << lane;
     const int rc = ransac_enqueue(ctx, d_p0, d_p1, N, d_idx, sampler, seed, it0, H, threshold, d_record, d_mask, d_counts,
                                   d_errsums, d_F_all, false, caller_errsums != nullptr);
     ctx->cur = ctx->stream;

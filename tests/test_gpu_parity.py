@@ -496,6 +496,76 @@ def test_carried_selections_equal_separate_launches(ctx):
         ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_carried_selection_random_sequences(ctx, seed):
+    """Long random sequences of calls with several in flight: shapes that carry their selection and shapes that do not
+    (small N, long H, per-hypothesis outputs asked for), both samplers, with and without a mask, waits at random points
+    and changes of the number of calls in flight - every call returns what it returns on its own.  Exercises the two
+    scratch sets per internal stream (a carried selection reads one while the next call writes the other), their growth
+    while selections are pending, and the flush paths."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    lib = ctx.lib
+    rng = np.random.default_rng(seed)
+    pairs = {}
+    for N in (4096, 9000, 3000, 2049, 700):
+        d = synth.make_pair(N, 0.3, seed=100 + N)
+        n0, _ = so.normalize_points(d["pts0"])
+        n1, _ = so.normalize_points(d["pts1"])
+        pairs[N] = (torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev))
+    shapes = [(4096, 2048), (4096, 8), (9000, 4096), (3000, 1000), (2049, 2050), (700, 300), (4096, 6000), (3000, 2063), (9000, 500)]
+
+    def issue(call, rec, mask, counts):
+        N, H, sampler, it0, with_mask, with_counts = call
+        p0, p1 = pairs[N]
+        ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, sampler, _lib.SEED_BASE, it0, H,
+                                        _lib.DEFAULT_THRESHOLD, rec.data_ptr(), mask.data_ptr() if with_mask else None,
+                                        counts.data_ptr() if with_counts else None, None, None))
+
+    calls = []
+    for _ in range(240):
+        N, H = shapes[int(rng.integers(len(shapes)))]
+        calls.append((N, H, int(rng.integers(2)), int(rng.integers(0, 3)) * 7, bool(rng.integers(2)), rng.random() < 0.15))
+    want = {}
+    try:
+        ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
+        for c in set(calls):
+            rec = torch.full((_lib.REC_LEN,), -3.0, dtype=torch.float64, device=dev)
+            mask = torch.full((c[0],), 9, dtype=torch.uint8, device=dev)
+            counts = torch.full((c[1],), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            issue(c, rec, mask, counts)
+            ctx.check(lib.slam_synchronize(ctx.handle))
+            want[c] = (rec.cpu().numpy(), mask.cpu().numpy(), counts.cpu().numpy())
+        ctx.check(lib.slam_set_concurrency(ctx.handle, 4))
+        # (output buffers are made and filled before anything is issued: torch fills them on a stream of its own, which
+        # is not ordered with the library's)
+        bufs = [(torch.full((_lib.REC_LEN,), -3.0, dtype=torch.float64, device=dev),
+                 torch.full((c[0],), 9, dtype=torch.uint8, device=dev),
+                 torch.full((c[1],), -1, dtype=torch.int32, device=dev)) for c in calls]
+        torch.cuda.synchronize()
+        pending = []
+        for k, c in enumerate(calls):
+            rec, mask, counts = bufs[k]
+            issue(c, rec, mask, counts)
+            pending.append((k, c, rec, mask, counts))
+            r = rng.random()
+            if r < 0.08 or k == len(calls) - 1:
+                ctx.check(lib.slam_synchronize(ctx.handle))
+                for kk, cc, rr, mm, nn in pending:
+                    w = want[cc]
+                    assert np.array_equal(rr.cpu().numpy(), w[0]), (kk, cc)
+                    if cc[4]:
+                        assert np.array_equal(mm.cpu().numpy(), w[1]), (kk, cc)
+                    if cc[5]:
+                        assert np.array_equal(nn.cpu().numpy(), w[2]), (kk, cc)
+                pending = []
+                if r < 0.03:
+                    ctx.check(lib.slam_set_concurrency(ctx.handle, int(rng.integers(2, 5))))
+    finally:
+        ctx.check(lib.slam_set_concurrency(ctx.handle, 1))
+
+
 @pytest.mark.parametrize("N,H,sampler", [(4096, 2048, 0), (4096, 2050, 1), (3000, 2063, 1), (9000, 4096, 0), (2049, 4000, 1)])
 def test_sixteen_hypotheses_per_workgroup_equal_eight(ctx, N, H, sampler):
     """With several calls in flight the fused kernel gives a workgroup sixteen hypotheses instead of eight (large shape):
@@ -517,6 +587,7 @@ def test_sixteen_hypotheses_per_workgroup_equal_eight(ctx, N, H, sampler):
         counts = torch.full((H,), -1, dtype=torch.int32, device=dev)
         errsums = torch.full((H,), -1.0, dtype=torch.float64, device=dev)
         F = torch.full((H, 9), -1.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()  # (torch fills on a stream of its own, not ordered with the library's)
         for _ in range(2):  # (the second call of a pair lands on another internal stream)
             ctx.check(lib.slam_ransac_f_dev(ctx.handle, p0.data_ptr(), p1.data_ptr(), N, None, smp, _lib.SEED_BASE, 0, H,
                                             _lib.DEFAULT_THRESHOLD, rec.data_ptr(), mask.data_ptr(), counts.data_ptr(),

@@ -245,7 +245,11 @@ def main():
     ss_med = float(np.median(ss))
     steady = {"workload": "the headline step in bursts of 2000 (same brackets around each burst)", "steps_per_burst": SS_STEPS,
               "bursts": SS_BURSTS, "ms_per_step": ss_med * 1e3, "ms_per_step_min": float(ss.min()) * 1e3,
-              "ms_per_step_max": float(ss.max()) * 1e3, "hypotheses_per_sec": world * N_HYP / ss_med,
+              "ms_per_step_max": float(ss.max()) * 1e3,
+              # the device has two step rates with four calls in flight: one steady to the percent, one 7-13 % slower whose
+              # bursts scatter; the spread of the bursts tells which one this record was taken in
+              "state": "steady" if float(ss.max() - ss.min()) < 0.03 * ss_med else "noisy",
+              "hypotheses_per_sec": world * N_HYP / ss_med,
               "residual_evals_per_sec": world * N_HYP * N_MATCHES / ss_med}
     # the same K steps strictly one after the other (one stream): the latency of a single call
     ctx.check(lib.slam_set_concurrency(ctx.handle, 1))

@@ -157,13 +157,16 @@ def main():
     def stop_clock():
         """Closing bracket: the library's own synchronisation first (with several calls in flight it still holds the
         last selections back, to be carried by a next call's kernel: slam_synchronize launches them and waits for
-        every internal stream), then the device, then the other ranks; then the clock is read."""
+        every internal stream), then the device; the clock is read; then the other ranks (barrier + synchronise)."""
         ctx.check(lib.slam_synchronize(ctx.handle))
         torch.cuda.synchronize()
+        t_done = time.perf_counter()   # this rank's K steps are complete; the burst lasts as long as the slowest rank (MAX below)
         if use_dist:
+            # the closing barrier still brackets the region (the next burst starts together), but its own latency - an
+            # RCCL collective and a host wait, tens of microseconds against a 20-step burst of 120 - is not the job's
             dist.barrier()
             torch.cuda.synchronize()
-        return time.perf_counter()
+        return t_done
 
     # ---- inputs: one frame pair per rank, normalised as the reference's caller does, resident in HBM
     pair = synth.make_pair(N_MATCHES, OUTLIERS, seed=2 + rank)

@@ -185,6 +185,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
             }
             const f32x2 nrc2 = {-(float)(rcut * rcut), 0.f};
             const int left = (ngroups - 1 - g) / (nslots * WAVES);  // groups after this one
+            // Sign bits of d, one per turn: each slice shifts its PPL bits in from below (turn k lands on bit PPL - 1 - k
+            // of the lowest PPL), and the word is counted when it is full, every 32 / PPL slices, not per slice.
+            constexpr int FLUSH_EVERY = 32 / PPL;
+            constexpr unsigned int SLICE_MASK = (1u << PPL) - 1u;
+            unsigned int bits[HG];
+#pragma unroll
+            for (int h = 0; h < HG; ++h) bits[h] = 0u;
+            const bool full_chunk = base + CH <= N;  // (uniform) every turn of every lane holds a match
 #pragma unroll 1
             for (int w = 0; w < SLAM_SLICES; ++w) {
                 {   // wave priority by the work that is left, as in k_score_lds
@@ -194,10 +202,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
                     else if (rem >= 2) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
-                unsigned int bits[HG];  // sign bits of d, one per turn of this slice (bit set: inside, if certain)
                 float mind[HG];         // smallest |d| of this lane's turns of the slice
 #pragma unroll
-                for (int h = 0; h < HG; ++h) { bits[h] = 0u; mind[h] = __builtin_inff(); }
+                for (int h = 0; h < HG; ++h) mind[h] = __builtin_inff();
 #pragma unroll
                 for (int q = 0; q < PAIRS; ++q) {
                     const float4 A = s_m[w][q][0][lane], B = s_m[w][q][1][lane];
@@ -216,21 +223,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
                         bits[h] = __builtin_amdgcn_alignbit(bits[h], __float_as_uint(d.y), 31);
                     }
                 }
-                // Turns of this lane that hold no match (beyond N; staged as NaN, which min3 skips) are masked out of the
-                // sign bits: turn k was shifted in k-th, so it sits at bit PPL - 1 - k.  (Non-finite REAL coordinates make
-                // the chunk's band infinite at staging, so every slice of such a chunk is counted in float64 below.)
-                const int nl = N - base - w * 64 - lane;  // > k * 512  <=>  turn k holds a match
-                const int live_turns = max(0, min(PPL, (nl + 64 * SLAM_SLICES - 1) / (64 * SLAM_SLICES)));
-                const unsigned int live_bits = ((1u << live_turns) - 1u) << (PPL - live_turns);
+                if (!full_chunk) {
+                    // Turns of this lane that hold no match (beyond N; staged as NaN, which min3 skips) are cleared from
+                    // the slice's bits.  (Non-finite REAL coordinates make the chunk's band infinite at staging, so every
+                    // slice of such a chunk is counted in float64 below.)
+                    const int nl = N - base - w * 64 - lane;  // > k * 512  <=>  turn k holds a match
+                    const int live_turns = max(0, min(PPL, (nl + 64 * SLAM_SLICES - 1) / (64 * SLAM_SLICES)));
+                    const unsigned int live_bits = ((1u << live_turns) - 1u) << (PPL - live_turns);
+#pragma unroll
+                    for (int h = 0; h < HG; ++h) bits[h] &= ~SLICE_MASK | live_bits;
+                }
 #pragma unroll
                 for (int h = 0; h < HG; ++h) {
-                    int n = __popc(bits[h] & live_bits);
                     if (__any(mind[h] < w2[h])) {  // (wave-uniform, rare) some lane is inside the band: the slice again in
-                        ++band_seen;               // float64, as the float64 kernels evaluate it
-                        const double* Fd = Fall + (size_t)min(h0 + h, H - 1) * 9;
+                        ++band_seen;               // float64, as the float64 kernels evaluate it; its bits stay in the word
+                        const double* Fd = Fall + (size_t)min(h0 + h, H - 1) * 9;   // and the difference is added
                         const double f0 = Fd[0], f1 = Fd[1], f2 = Fd[2], f3 = Fd[3], f4 = Fd[4], f5 = Fd[5], f6 = Fd[6], f7 = Fd[7],
                                      f8 = Fd[8];
-                        n = 0;
+                        int n = 0;
 #pragma unroll 1
                         for (int k = 0; k < PPL; ++k) {
                             const int i = base + k * 64 * SLAM_SLICES + w * 64 + lane;
@@ -238,8 +248,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_count_f32(const double2* __restr
                             const double r = residual<false>(a.x, a.y, b.x, b.y, f0, f1, f2, f3, f4, f5, f6, f7, f8);
                             n += (i < N && fabs(r) < rcut) ? 1 : 0;
                         }
+                        cl[h] += n - __popc(bits[h] & SLICE_MASK);
                     }
-                    cl[h] += n;
+                }
+                if ((w + 1) % FLUSH_EVERY == 0 || w == SLAM_SLICES - 1) {  // (uniform)
+#pragma unroll
+                    for (int h = 0; h < HG; ++h) { cl[h] += __popc(bits[h]); bits[h] = 0u; }
                 }
             }
             int cnt[HG];  // wave totals

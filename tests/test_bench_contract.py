@@ -46,6 +46,9 @@ def test_bench_line_contract(path):
     assert r["bound_unit"] == "valu_fp64"
     s_ = d["aux_steady_state"]
     assert s_["steps_per_burst"] == 2000 and s_["ms_per_step_min"] <= s_["ms_per_step"] <= s_["ms_per_step_max"]
+    if "state" in s_:   # (lines written since the field exists) which of the device's two step rates the record was taken in
+        spread = (s_["ms_per_step_max"] - s_["ms_per_step_min"]) / s_["ms_per_step"]
+        assert s_["state"] == ("steady" if spread < 0.03 else "noisy")
     if "cpu_baseline" in d:  # (the short runs of a profile set skip it: --no-cpu-baseline)
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["unit"] == "hypotheses/s" and c["cores"] == 1 and c["value"] > 0

@@ -983,22 +983,24 @@ extern "C" int slam_ransac_f(slam_ctx* ctx, const double* p0, const double* p1, 
         SLAM_HIP(ctx, hipMemcpyAsync(ctx->idx.p, idx, (size_t)H * 8 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         d_idx = (const int32_t*)ctx->idx.p;
     }
-    uint8_t* d_mask = nullptr;
-    if (mask) { SLAM_TRY(slam_reserve(ctx, ctx->mask, (size_t)N)); d_mask = (uint8_t*)ctx->mask.p; }
+    // The record and the mask share one device buffer (record first, mask 256 bytes in), so that ONE copy brings both
+    // back: a second small download costs 3 us of a 40 us call.
+    SLAM_TRY(slam_reserve(ctx, ctx->mask, 256 + (size_t)N));
+    double* d_rec = (double*)ctx->mask.p;
+    uint8_t* d_mask = mask ? (uint8_t*)ctx->mask.p + 256 : nullptr;
     SLAM_TRY(slam_reserve(ctx, ctx->F, (size_t)H * 9 * sizeof(double)));
     SLAM_TRY(slam_reserve(ctx, ctx->counts, (size_t)H * sizeof(int32_t)));
     SLAM_TRY(slam_reserve(ctx, ctx->errsums, (size_t)H * sizeof(double)));
-    SLAM_TRY(ransac_enqueue(ctx, d0, d1, N, d_idx, sampler, seed, it0, H, threshold, (double*)ctx->record.p, d_mask,
+    SLAM_TRY(ransac_enqueue(ctx, d0, d1, N, d_idx, sampler, seed, it0, H, threshold, d_rec, d_mask,
                             (int32_t*)ctx->counts.p, (double*)ctx->errsums.p, (double*)ctx->F.p, false, errsums != nullptr));
     // record and mask come back through the pinned area (behind the staged points) and are handed over after the
     // synchronisation of check_flags(); the optional per-hypothesis arrays go directly
     char* h_out = stage_area(ctx, out_at + 256 + (size_t)N);
     if (h_out) {
         h_out += out_at;
-        SLAM_HIP(ctx, hipMemcpyAsync(h_out, ctx->record.p, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (mask) SLAM_HIP(ctx, hipMemcpyAsync(h_out + 256, d_mask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(h_out, d_rec, mask ? 256 + (size_t)N : SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     } else {
-        SLAM_HIP(ctx, hipMemcpyAsync(record, ctx->record.p, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(ctx, hipMemcpyAsync(record, d_rec, SLAM_REC_LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (mask) SLAM_HIP(ctx, hipMemcpyAsync(mask, d_mask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (counts) SLAM_HIP(ctx, hipMemcpyAsync(counts, ctx->counts.p, (size_t)H * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
